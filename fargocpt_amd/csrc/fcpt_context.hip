@@ -1,0 +1,705 @@
+// Context management and the device part of the C ABI (include/fargocpt_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fcpt_kernels.h"
+
+using namespace fcpt;
+
+#define HIPCHK(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FCPT_EHIP;                                                               \
+        }                                                                                   \
+    } while (0)
+
+struct fcpt_ctx {
+    fcpt_desc d;
+    fcpt_split s;
+    HostGeometry geo;
+    std::vector<double> radii;
+    Dev P;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    double *d_cs_ring = nullptr;
+    double *grid[FCPT_F_COUNT] = {};
+    DampRange damp[4][2]; // [vrad, vaz, sigma, energy][inner, outer]
+    bool potential_valid = false;
+    DevClock *h_clk = nullptr; // pinned staging copy
+};
+
+namespace {
+
+template <class T> int dev_alloc(fcpt_ctx *c, T **p, size_t n)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+        return FCPT_ENOMEM;
+    }
+    e = hipMemset(q, 0, (n ? n : 1) * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMemset failed: %s", hipGetErrorString(e));
+        return FCPT_EHIP;
+    }
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return FCPT_OK;
+}
+
+int dev_upload(fcpt_ctx *c, const double **dst, const std::vector<double> &src)
+{
+    double *p = nullptr;
+    if (int rc = dev_alloc(c, &p, src.size()))
+        return rc;
+    hipError_t e = hipMemcpy(p, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("hipMemcpy H2D failed: %s", hipGetErrorString(e));
+        return FCPT_EHIP;
+    }
+    *dst = p;
+    return FCPT_OK;
+}
+
+// damping.cpp:311-427: which rows a damping call touches and its time scale
+DampRange damp_range(const fcpt_ctx *c, int is_vector, int type, int outer)
+{
+    DampRange r;
+    r.lo = 0;
+    r.hi = -1;
+    r.type = type;
+    r.rlim = r.redge = r.tau = 0;
+    if (!c->d.damping || type == FCPT_DAMP_NONE)
+        return r;
+    const fcpt_desc &d = c->d;
+    const std::vector<double> &radius = is_vector ? c->geo.Rinf : c->geo.Rmed;
+    const int nr = c->s.nr;
+    const int size_radial = is_vector ? nr + 1 : nr;
+    auto clamp = [&](int id) {
+        const int mx = nr - (is_vector ? 0 : 1);
+        return id < 0 ? 0 : (id > mx ? mx : id);
+    };
+    auto omega_k = [&](double rr) { return std::sqrt(d.G * d.hydro_center_mass / (rr * rr * rr)); };
+    if (!outer) {
+        if (!((d.damping_inner_limit > 1.0) && (radius[0] < d.rmin * d.damping_inner_limit)))
+            return r;
+        const double rl = d.rmin * d.damping_inner_limit;
+        const int limit = clamp(is_vector ? rinf_id(d, c->s, c->geo, rl) : rmed_id(d, c->s, c->geo, rl));
+        r.lo = 0;
+        r.hi = limit;
+        r.rlim = rl;
+        r.redge = d.rmin;
+        r.tau = d.damping_time_factor * 2.0 * M_PI / omega_k(d.rmin);
+    } else {
+        if (!((d.damping_outer_limit < 1.0) && (radius[size_radial - 1] > d.rmax * d.damping_outer_limit)))
+            return r;
+        const double rl = d.rmax * d.damping_outer_limit;
+        const int limit =
+            clamp((is_vector ? rinf_id(d, c->s, c->geo, rl) : rmed_id(d, c->s, c->geo, rl)) + 1);
+        r.lo = limit;
+        r.hi = size_radial - 1;
+        r.rlim = rl;
+        r.redge = d.rmax;
+        r.tau = d.damping_time_factor * 2.0 * M_PI / omega_k(d.damping_time_radius_outer);
+    }
+    return r;
+}
+
+// boundary_conditions.cpp:65-114
+void apply_boundary(fcpt_ctx *c, bool final)
+{
+    const Dev &P = c->P;
+    if (final && c->d.damping) {
+        // damping.cpp:754-774, order of damping_vector: vrad, vaz, sigma, energy
+        for (int o = 0; o < 2; ++o)
+            launch_damping(P, P.vrad, P.vrad0, P.Rinf, c->damp[0][o], 0, c->stream);
+        for (int o = 0; o < 2; ++o)
+            launch_damping(P, P.vazi, P.vazi0, P.Rmed, c->damp[1][o], 0, c->stream);
+        for (int o = 0; o < 2; ++o)
+            launch_damping(P, P.sigma, P.sigma0, P.Rmed, c->damp[2][o], 1, c->stream);
+        if (P.adiabatic)
+            for (int o = 0; o < 2; ++o)
+                launch_damping(P, P.energy, P.energy0, P.Rmed, c->damp[3][o], 0, c->stream);
+    }
+    launch_boundary(P, c->stream);
+}
+
+int copy_initial_values(fcpt_ctx *c)
+{
+    const Dev &P = c->P;
+    const size_t ns = (size_t)P.nr * P.nphi * sizeof(double), nv = (size_t)(P.nr + 1) * P.nphi * sizeof(double);
+    HIPCHK(hipMemcpyAsync(P.vrad0, P.vrad, nv, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(P.vazi0, P.vazi, ns, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(P.sigma0, P.sigma, ns, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(P.energy0, P.energy, ns, hipMemcpyDeviceToDevice, c->stream));
+    return FCPT_OK;
+}
+
+int read_clock(fcpt_ctx *c, DevClock *out)
+{
+    HIPCHK(hipMemcpyAsync(c->h_clk, c->P.clk, sizeof(DevClock), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = *c->h_clk;
+    return FCPT_OK;
+}
+
+// the gas part of step_Euler up to Transport (simulation.cpp:167-217)
+void enqueue_step(fcpt_ctx *c)
+{
+    const Dev &P = c->P;
+    hipStream_t st = c->stream;
+    if (P.adiabatic || !c->potential_valid) {
+        launch_potential(P, st); // CalculateNbodyPotential; static when H and the bodies are
+        c->potential_valid = true;
+    }
+    launch_source(P, st);
+    launch_artificial_viscosity(P, st);
+    launch_recalculate_viscosity(P, st);
+    launch_stress(P, st);
+    launch_viscous_update(P, st);
+    if (P.adiabatic)
+        launch_substep3(P, 1, st);
+    apply_boundary(c, false);
+    launch_transport(P, st);
+    launch_clock_advance(P.clk, st);
+}
+
+void enqueue_post(fcpt_ctx *c)
+{
+    apply_boundary(c, true);
+    launch_derived(c->P, c->stream);
+}
+
+} // namespace
+
+extern "C" {
+
+int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
+{
+    if (!d || !radii || !out) {
+        set_error("null argument");
+        return FCPT_EINVAL;
+    }
+    if (d->struct_size != sizeof(fcpt_desc) || d->abi_version != FCPT_ABI_VERSION) {
+        set_error("descriptor ABI mismatch: size %u (expected %zu), version %u (expected %d)", d->struct_size,
+                  sizeof(fcpt_desc), d->abi_version, FCPT_ABI_VERSION);
+        return FCPT_EINVAL;
+    }
+    if (d->stabilize_viscosity != 0) {
+        set_error("StabilizeViscosity != 0 is not supported");
+        return FCPT_EINVAL;
+    }
+    if (!d->body_force_from_potential) {
+        set_error("BodyForceFromPotential: no is not supported");
+        return FCPT_EINVAL;
+    }
+    if (d->integrator != FCPT_INTEGRATOR_EULER) {
+        set_error("Integrator: Leapfrog is not supported yet");
+        return FCPT_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available: the HIP path cannot run (there is no CPU fallback)");
+        return FCPT_ENODEV;
+    }
+    fcpt_ctx *c = new (std::nothrow) fcpt_ctx();
+    if (!c)
+        return FCPT_ENOMEM;
+    c->d = *d;
+    if (int rc = split_domain(*d, c->s)) {
+        delete c;
+        return rc;
+    }
+    const int nr = c->s.nr, nphi = d->nphi;
+    c->radii.assign(radii, radii + d->nr_global + FCPT_GEOM_PAD + 1);
+    build_geometry(*d, c->s, radii, c->geo);
+
+    Dev &P = c->P;
+    std::memset(&P, 0, sizeof(P));
+    P.nr = nr;
+    P.nphi = nphi;
+    P.dphi = c->geo.dphi;
+    P.invdphi = c->geo.invdphi;
+    int rc = FCPT_OK;
+#define UP(field) \
+    if (!rc)      \
+        rc = dev_upload(c, &P.field, c->geo.field);
+    UP(Rmed) UP(Rinf) UP(Rsup) UP(Surf) UP(InvRmed) UP(InvRinf) UP(InvSurf) UP(InvDiffRmed)
+    UP(InvDiffRsup) UP(InvDiffRsupRb)
+#undef UP
+    std::vector<double> cp(nphi), sp(nphi), cs_ring(nr);
+    for (int j = 0; j < nphi; ++j) { // SideEuler.cpp:60-63
+        cp[j] = std::cos(c->geo.dphi * (double)j);
+        sp[j] = std::sin(c->geo.dphi * (double)j);
+    }
+    for (int i = 0; i < nr; ++i) { // SourceEuler.cpp:1080-1088
+        const double vK = std::sqrt(d->G * d->hydro_center_mass / c->geo.Rmed[i]);
+        const double h = d->aspect_ratio * std::pow(c->geo.Rmed[i], d->flaring_index);
+        cs_ring[i] = h * vK;
+    }
+    if (!rc)
+        rc = dev_upload(c, &P.cosphi, cp);
+    if (!rc)
+        rc = dev_upload(c, &P.sinphi, sp);
+    const double *csr = nullptr;
+    if (!rc)
+        rc = dev_upload(c, &csr, cs_ring);
+    c->d_cs_ring = const_cast<double *>(csr);
+
+    const size_t ns = (size_t)nr * nphi, nv = (size_t)(nr + 1) * nphi;
+#define AL(field, n) \
+    if (!rc)         \
+        rc = dev_alloc(c, &P.field, (n));
+    AL(sigma, ns) AL(vrad, nv) AL(vazi, ns) AL(energy, ns)
+    AL(pressure, ns) AL(soundspeed, ns) AL(scale_height, ns) AL(viscosity, ns) AL(temperature, ns)
+    AL(potential, ns)
+    AL(sigma0, ns) AL(vrad0, nv) AL(vazi0, ns) AL(energy0, ns)
+    AL(qr, ns) AL(qphi, ns) AL(divv, ns) AL(trr, ns) AL(tpp, ns) AL(trp, nv) AL(qplus, ns) AL(qminus, ns)
+    AL(rmpA, ns) AL(rmmA, ns) AL(lpA, ns) AL(lmA, ns) AL(sigA, ns) AL(eA, ns)
+    AL(rmpB, ns) AL(rmmB, ns) AL(lpB, ns) AL(lmB, ns) AL(sigB, ns) AL(eB, ns)
+    AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1)
+#undef AL
+    if (!rc && hipHostMalloc((void **)&c->h_clk, sizeof(DevClock)) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        rc = FCPT_ENOMEM;
+    }
+    if (rc) {
+        fcpt_destroy(c);
+        return rc;
+    }
+    c->grid[FCPT_F_SIGMA] = P.sigma;
+    c->grid[FCPT_F_VRAD] = P.vrad;
+    c->grid[FCPT_F_VAZI] = P.vazi;
+    c->grid[FCPT_F_ENERGY] = P.energy;
+    c->grid[FCPT_F_PRESSURE] = P.pressure;
+    c->grid[FCPT_F_SOUNDSPEED] = P.soundspeed;
+    c->grid[FCPT_F_SCALE_HEIGHT] = P.scale_height;
+    c->grid[FCPT_F_VISCOSITY] = P.viscosity;
+    c->grid[FCPT_F_TEMPERATURE] = P.temperature;
+    c->grid[FCPT_F_POTENTIAL] = P.potential;
+    c->grid[FCPT_F_SIGMA0] = P.sigma0;
+    c->grid[FCPT_F_VRAD0] = P.vrad0;
+    c->grid[FCPT_F_VAZI0] = P.vazi0;
+    c->grid[FCPT_F_ENERGY0] = P.energy0;
+    c->grid[FCPT_F_QPLUS] = P.qplus;
+    c->grid[FCPT_F_QMINUS] = P.qminus;
+
+    P.zero_no_ghost = c->s.zero_no_ghost;
+    P.one_no_ghost_vr = c->s.one_no_ghost_vr;
+    P.max_no_ghost = c->s.max_no_ghost;
+    P.maxmo_no_ghost_vr = c->s.maxmo_no_ghost_vr;
+    P.first_active = c->s.radial_first_active;
+    P.active_size = c->s.radial_active_size;
+    P.is_first = c->s.is_first;
+    P.is_last = c->s.is_last;
+    P.adiabatic = d->eos == FCPT_EOS_IDEAL;
+    P.art_visc = d->artificial_viscosity;
+    P.art_visc_dissipation = d->artificial_viscosity_dissipation;
+    P.heating_viscous = d->heating_viscous;
+    P.fast_transport = d->fast_transport;
+    P.limiter = d->flux_limiter;
+    P.leapfrog = d->integrator == FCPT_INTEGRATOR_LEAPFROG;
+    P.alpha_viscosity = d->viscous_alpha > 0;
+    P.gamma = d->adiabatic_index;
+    P.mu = d->mu;
+    P.Rgas = d->Rgas;
+    P.G = d->G;
+    P.Mc = d->hydro_center_mass;
+    P.sigma_sb = d->sigma_sb;
+    P.c_light = d->c_light;
+    P.aspect_ratio = d->aspect_ratio;
+    P.flaring_index = d->flaring_index;
+    P.tmin = d->minimum_temperature;
+    P.tmax = d->maximum_temperature;
+    P.sigma_floor_abs = d->sigma_floor * d->sigma0;
+    P.sigma_floor_rel = d->sigma_floor;
+    P.sigma0_val = d->sigma0;
+    P.alpha = d->viscous_alpha;
+    P.nu_const = d->constant_viscosity;
+    P.radial_viscosity_factor = d->radial_viscosity_factor;
+    P.art_visc_factor = d->artificial_viscosity_factor;
+    P.heating_viscous_factor = d->heating_viscous_factor;
+    P.omega_frame = d->omega_frame;
+    P.thickness_smoothing = d->thickness_smoothing;
+    P.cfl = d->cfl;
+    P.cfl_max_var = d->cfl_max_var;
+    P.heating_cooling_cfl_limit = d->heating_cooling_cfl_limit;
+    P.monitor_timestep = d->monitor_timestep;
+    for (int k = 0; k < 2; ++k) {
+        P.bc_sigma[k] = d->bc_sigma[k];
+        P.bc_energy[k] = d->bc_energy[k];
+        P.bc_vrad[k] = d->bc_vrad[k];
+        P.bc_vaz[k] = d->bc_vaz[k];
+        P.kep_vaz[k] = d->keplerian_vaz_factor[k];
+        P.kep_vrad[k] = d->keplerian_vrad_factor[k];
+    }
+    // default body: the central star at the origin
+    P.nbodies = 1;
+    P.bm[0] = d->hydro_center_mass;
+
+    const int dtype[4][2] = {{d->damp_vrad[0], d->damp_vrad[1]},
+                             {d->damp_vaz[0], d->damp_vaz[1]},
+                             {d->damp_sigma[0], d->damp_sigma[1]},
+                             {d->damp_energy[0], d->damp_energy[1]}};
+    for (int q = 0; q < 4; ++q)
+        for (int o = 0; o < 2; ++o)
+            c->damp[q][o] = damp_range(c, q == 0, dtype[q][o], o);
+
+    DevClock clk;
+    std::memset(&clk, 0, sizeof(clk));
+    clk.last_dt = d->first_dt; // Interpret.cpp:86
+    clk.dt = d->first_dt;
+    if (hipMemcpy(P.clk, &clk, sizeof(clk), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("hipMemcpy of the clock failed");
+        fcpt_destroy(c);
+        return FCPT_EHIP;
+    }
+    *out = c;
+    return FCPT_OK;
+}
+
+int fcpt_destroy(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_OK;
+    for (void *p : c->allocs)
+        (void)hipFree(p);
+    if (c->h_clk)
+        (void)hipHostFree(c->h_clk);
+    delete c;
+    return FCPT_OK;
+}
+
+int fcpt_set_stream(fcpt_ctx *c, void *hip_stream)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    c->stream = (hipStream_t)hip_stream;
+    return FCPT_OK;
+}
+
+int fcpt_synchronize(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FCPT_OK;
+}
+
+int fcpt_get_split(const fcpt_ctx *c, fcpt_split *out)
+{
+    if (!c || !out)
+        return FCPT_EINVAL;
+    *out = c->s;
+    return FCPT_OK;
+}
+
+int fcpt_get_clock(const fcpt_ctx *cc, fcpt_clock *out)
+{
+    fcpt_ctx *c = const_cast<fcpt_ctx *>(cc);
+    if (!c || !out)
+        return FCPT_EINVAL;
+    DevClock k;
+    if (int rc = read_clock(c, &k))
+        return rc;
+    out->time = k.time;
+    out->last_dt = k.last_dt;
+    out->n_hydro_iter = k.n_hydro_iter;
+    out->n_monitor = k.n_monitor;
+    out->n_snapshot = k.n_snapshot;
+    return FCPT_OK;
+}
+
+int fcpt_set_clock(fcpt_ctx *c, const fcpt_clock *in)
+{
+    if (!c || !in)
+        return FCPT_EINVAL;
+    DevClock k;
+    if (int rc = read_clock(c, &k))
+        return rc;
+    k.time = in->time;
+    k.last_dt = in->last_dt;
+    k.n_hydro_iter = in->n_hydro_iter;
+    k.n_monitor = in->n_monitor;
+    k.n_snapshot = in->n_snapshot;
+    *c->h_clk = k;
+    HIPCHK(hipMemcpyAsync(c->P.clk, c->h_clk, sizeof(DevClock), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FCPT_OK;
+}
+
+static size_t grid_count(const fcpt_ctx *c, int32_t f)
+{
+    const bool vec = f == FCPT_F_VRAD || f == FCPT_F_VRAD0;
+    return (size_t)(c->s.nr + (vec ? 1 : 0)) * c->d.nphi;
+}
+
+int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
+{
+    if (!c || !host || f < 0 || f >= FCPT_F_COUNT) {
+        set_error("bad argument to fcpt_upload");
+        return FCPT_EINVAL;
+    }
+    HIPCHK(hipMemcpyAsync(c->grid[f], host, grid_count(c, f) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (f == FCPT_F_SCALE_HEIGHT)
+        c->potential_valid = false;
+    return FCPT_OK;
+}
+
+int fcpt_download(fcpt_ctx *c, int32_t f, double *host)
+{
+    if (!c || !host || f < 0 || f >= FCPT_F_COUNT) {
+        set_error("bad argument to fcpt_download");
+        return FCPT_EINVAL;
+    }
+    HIPCHK(hipMemcpyAsync(host, c->grid[f], grid_count(c, f) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FCPT_OK;
+}
+
+int fcpt_device_ptr(fcpt_ctx *c, int32_t f, void **dptr, uint64_t *count)
+{
+    if (!c || !dptr || f < 0 || f >= FCPT_F_COUNT)
+        return FCPT_EINVAL;
+    *dptr = c->grid[f];
+    if (count)
+        *count = grid_count(c, f);
+    return FCPT_OK;
+}
+
+int fcpt_set_bodies(fcpt_ctx *c, int32_t n, const double *x, const double *y, const double *m,
+                    const double *rsm, double ix, double iy)
+{
+    if (!c || n < 0 || n > FCPT_MAX_BODIES || (n > 0 && (!x || !y || !m))) {
+        set_error("bad argument to fcpt_set_bodies (at most %d bodies)", FCPT_MAX_BODIES);
+        return FCPT_EINVAL;
+    }
+    Dev &P = c->P;
+    P.nbodies = n;
+    for (int k = 0; k < n; ++k) {
+        P.bx[k] = x[k];
+        P.by[k] = y[k];
+        P.bm[k] = m[k];
+        P.brsm[k] = rsm ? rsm[k] : 0.0;
+    }
+    P.indirect_x = ix;
+    P.indirect_y = iy;
+    c->potential_valid = false;
+    return FCPT_OK;
+}
+
+// init_euler (SourceEuler.cpp:251-285) + the tail of init_physics (init.cpp:337-341)
+int fcpt_init_physics(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    const Dev &P = c->P;
+    hipStream_t st = c->stream;
+    if (!P.adiabatic) {
+        launch_iso_cs_h(P, c->d_cs_ring, st);
+        launch_pressure(P, st);
+        launch_temperature(P, st);
+    } else {
+        launch_temperature(P, st);
+        launch_recalculate_viscosity(P, st); // cs, H (and nu when alpha)
+        launch_pressure(P, st);
+    }
+    launch_viscosity_field(P, st);
+    // compute_heating_cooling_for_CFL (SourceEuler.cpp:1507-1547) runs before the velocities
+    // are initialised (init.cpp:331-332): the gas is at rest, the stress tensor vanishes and
+    // Q+ = Q- = 0, which is what the zero-filled grids already hold.
+    const size_t ns = (size_t)P.nr * P.nphi * sizeof(double);
+    HIPCHK(hipMemsetAsync(P.qplus, 0, ns, st));
+    HIPCHK(hipMemsetAsync(P.qminus, 0, ns, st));
+    if (int rc = copy_initial_values(c))
+        return rc;
+    apply_boundary(c, false);
+    if (int rc = copy_initial_values(c))
+        return rc;
+    c->potential_valid = false;
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_cfl(fcpt_ctx *c, double *dt_local)
+{
+    if (!c || !dt_local)
+        return FCPT_EINVAL;
+    launch_cfl(c->P, c->stream);
+    HIPCHK(hipGetLastError());
+    DevClock k;
+    if (int rc = read_clock(c, &k))
+        return rc;
+    double v;
+    std::memcpy(&v, &k.cfl_bits, sizeof(v));
+    *dt_local = v;
+    return FCPT_OK;
+}
+
+int fcpt_calculate_timestep(fcpt_ctx *c, double cfl_dt_global, double *dt)
+{
+    if (!c || !dt)
+        return FCPT_EINVAL;
+    launch_clock_policy(c->P.clk, c->d.cfl_max_var, 0, cfl_dt_global, c->stream);
+    DevClock k;
+    if (int rc = read_clock(c, &k))
+        return rc;
+    *dt = k.last_dt;
+    return FCPT_OK;
+}
+
+int fcpt_snap_to_monitor(const fcpt_ctx *cc, double cfl_dt, double *step_dt)
+{
+    fcpt_ctx *c = const_cast<fcpt_ctx *>(cc);
+    if (!c || !step_dt)
+        return FCPT_EINVAL;
+    DevClock k;
+    if (int rc = read_clock(c, &k))
+        return rc;
+    // simulation.cpp:528-540
+    const double time_next_monitor = (k.n_monitor + 1) * c->d.monitor_timestep;
+    const double time_left_till_write = time_next_monitor - k.time;
+    const bool overshoot = cfl_dt > time_left_till_write;
+    const double dt_stretch_factor = 0.05;
+    const bool almost_there = time_left_till_write < cfl_dt * (1 + dt_stretch_factor);
+    *step_dt = (overshoot || almost_there) ? time_left_till_write : cfl_dt;
+    return FCPT_OK;
+}
+
+int fcpt_step(fcpt_ctx *c, double dt)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    launch_clock_set_dt(c->P.clk, dt, c->stream);
+    enqueue_step(c);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_post(fcpt_ctx *c, double dt)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    launch_clock_set_dt(c->P.clk, dt, c->stream);
+    enqueue_post(c);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_apply_boundary(fcpt_ctx *c, double dt, int32_t final)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    launch_clock_set_dt(c->P.clk, dt, c->stream);
+    apply_boundary(c, final != 0);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_exchange_count(const fcpt_ctx *c, uint64_t *count)
+{
+    if (!c || !count)
+        return FCPT_EINVAL;
+    *count = (uint64_t)(c->d.eos == FCPT_EOS_IDEAL ? 4 : 3) * c->d.nphi * FCPT_OVERLAP;
+    return FCPT_OK;
+}
+
+// commbound.cpp:108-125: rows [7,14) -> inner neighbour, rows [nr-14,nr-7) -> outer
+int fcpt_exchange_pack(fcpt_ctx *c, double *send_inner, double *send_outer)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    const Dev &P = c->P;
+    const size_t l = (size_t)FCPT_OVERLAP * P.nphi, lb = l * sizeof(double);
+    const size_t o = (size_t)(P.nr - 2 * FCPT_OVERLAP) * P.nphi;
+    const double *src[4] = {P.sigma, P.vrad, P.vazi, P.energy};
+    const int nq = P.adiabatic ? 4 : 3;
+    for (int q = 0; q < nq; ++q) {
+        if (send_inner)
+            HIPCHK(hipMemcpyAsync(send_inner + q * l, src[q] + l, lb, hipMemcpyDeviceToDevice, c->stream));
+        if (send_outer)
+            HIPCHK(hipMemcpyAsync(send_outer + q * l, src[q] + o, lb, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return FCPT_OK;
+}
+
+// commbound.cpp:163-180: inner neighbour's data -> rows [0,7), outer's -> rows [nr-7,nr)
+int fcpt_exchange_unpack(fcpt_ctx *c, const double *recv_inner, const double *recv_outer)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    const Dev &P = c->P;
+    const size_t l = (size_t)FCPT_OVERLAP * P.nphi, lb = l * sizeof(double);
+    const size_t oo = (size_t)(P.nr - FCPT_OVERLAP) * P.nphi;
+    double *dst[4] = {P.sigma, P.vrad, P.vazi, P.energy};
+    const int nq = P.adiabatic ? 4 : 3;
+    for (int q = 0; q < nq; ++q) {
+        if (recv_inner)
+            HIPCHK(hipMemcpyAsync(dst[q], recv_inner + q * l, lb, hipMemcpyDeviceToDevice, c->stream));
+        if (recv_outer)
+            HIPCHK(hipMemcpyAsync(dst[q] + oo, recv_outer + q * l, lb, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return FCPT_OK;
+}
+
+// sim::run's loop (simulation.cpp:515-553) for a single slab.
+int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    int64_t n = 0;
+    if (!snap) {
+        // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
+        for (; n < nsteps; ++n) {
+            launch_cfl(c->P, c->stream);
+            launch_clock_policy(c->P.clk, c->d.cfl_max_var, 1, 0.0, c->stream);
+            enqueue_step(c);
+            enqueue_post(c);
+        }
+        HIPCHK(hipGetLastError());
+    } else {
+        const double t_final = (double)c->d.nsnapshots * c->d.nmonitor * c->d.monitor_timestep;
+        for (; n < nsteps; ++n) {
+            DevClock k;
+            if (int rc = read_clock(c, &k))
+                return rc;
+            if (t_final > 0 && !(k.time < t_final))
+                break;
+            double cfl_dt, dt, step_dt;
+            if (int rc = fcpt_cfl(c, &cfl_dt))
+                return rc;
+            if (int rc = fcpt_calculate_timestep(c, cfl_dt, &dt))
+                return rc;
+            if (int rc = fcpt_snap_to_monitor(c, dt, &step_dt))
+                return rc;
+            const double time_next_monitor = (k.n_monitor + 1) * c->d.monitor_timestep;
+            if (int rc = fcpt_step(c, step_dt))
+                return rc;
+            if (int rc = fcpt_post(c, step_dt))
+                return rc;
+            if (int rc = read_clock(c, &k))
+                return rc;
+            const bool towrite = std::fabs(time_next_monitor - k.time) < 1e-6 * dt;
+            if (towrite) {
+                fcpt_clock hc = {k.time, k.last_dt, k.n_hydro_iter, k.n_monitor + 1, 0};
+                hc.n_snapshot = hc.n_monitor / (uint32_t)(c->d.nmonitor > 0 ? c->d.nmonitor : 1);
+                if (int rc = fcpt_set_clock(c, &hc))
+                    return rc;
+            }
+        }
+    }
+    if (done)
+        *done = n;
+    return FCPT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,97 @@
+// Internal declarations shared by the host and HIP translation units.
+#ifndef FCPT_INTERNAL_H
+#define FCPT_INTERNAL_H
+
+#include "../../include/fargocpt_hip.h"
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace fcpt {
+
+void set_error(const char *fmt, ...);
+
+// Radial 1-D arrays of one slab (src/global.h:62-79), nr + FCPT_GEOM_PAD + 1 entries.
+struct HostGeometry {
+    std::vector<double> Rmed, Rinf, Rsup, Surf, InvRmed, InvRinf, InvSurf, InvDiffRmed, InvDiffRsup,
+        InvDiffRsupRb;
+    double dphi = 0, invdphi = 0;
+    double cf_growth = 0, cf_inv_log_growth = 0, cf_opt_const = 0; // src/find_cell_id.cpp
+};
+
+int build_radii(const fcpt_desc &d, double *radii);
+int split_domain(const fcpt_desc &d, fcpt_split &out);
+void build_geometry(const fcpt_desc &d, const fcpt_split &s, const double *radii, HostGeometry &g);
+int rmed_id(const fcpt_desc &d, const fcpt_split &s, const HostGeometry &g, double r);
+int rinf_id(const fcpt_desc &d, const fcpt_split &s, const HostGeometry &g, double r);
+
+// Simulation clock as it lives in device memory; kernels read dt from here so a
+// step never needs a host round trip.
+struct DevClock {
+    double time;
+    double last_dt;
+    double dt;     // the step length currently in force
+    double cfl_dt; // result of the last CFL policy evaluation
+    unsigned long long cfl_bits; // running min of the CFL reduction (bit pattern of a positive double)
+    unsigned long long n_hydro_iter;
+    unsigned int n_monitor;
+    unsigned int n_snapshot;
+};
+
+// Per-row damping description, built on the host (damping.cpp:311-427).
+struct DampRange {
+    int lo, hi;      // inclusive row range, lo > hi = disabled
+    int type;        // FCPT_DAMP_*
+    double rlim, redge, tau;
+};
+
+// Everything a kernel needs: geometry, grids, parameters.  Passed by value.
+struct Dev {
+    int nr, nphi;
+    double dphi, invdphi;
+    // geometry
+    const double *Rmed, *Rinf, *Rsup, *Surf, *InvRmed, *InvRinf, *InvSurf, *InvDiffRmed, *InvDiffRsup,
+        *InvDiffRsupRb;
+    const double *cosphi, *sinphi; // cos/sin(dphi * j), j < nphi (SideEuler.cpp:60-63)
+    // state
+    double *sigma, *vrad, *vazi, *energy;
+    // derived
+    double *pressure, *soundspeed, *scale_height, *viscosity, *temperature, *potential;
+    // reference (t = 0) copies
+    double *sigma0, *vrad0, *vazi0, *energy0;
+    // source-step scratch
+    double *qr, *qphi, *divv, *trr, *tpp, *trp /* (nr+1) rows */, *qplus, *qminus;
+    // transport: momenta / density / energy, two sets (A: after pass 1, B: radial + final)
+    double *rmpA, *rmmA, *lpA, *lmA, *sigA, *eA;
+    double *rmpB, *rmmB, *lpB, *lmB, *sigB, *eB;
+    double *vmean;  // per ring <v_phi>
+    double *vconst; // per ring constant residual velocity
+    int *nshift;    // per ring integer shift
+    DevClock *clk;
+    // split
+    int zero_no_ghost, one_no_ghost_vr, max_no_ghost, maxmo_no_ghost_vr, first_active, active_size;
+    int is_first, is_last;
+    // parameters
+    int adiabatic, art_visc, art_visc_dissipation, heating_viscous, fast_transport, limiter, leapfrog;
+    int alpha_viscosity;
+    double gamma, mu, Rgas, G, Mc, sigma_sb, c_light, aspect_ratio, flaring_index;
+    double tmin, tmax, sigma_floor_abs, sigma_floor_rel, sigma0_val;
+    double alpha, nu_const, radial_viscosity_factor, art_visc_factor, heating_viscous_factor;
+    double omega_frame, thickness_smoothing, cfl, cfl_max_var, heating_cooling_cfl_limit;
+    double monitor_timestep;
+    int bc_sigma[2], bc_energy[2], bc_vrad[2], bc_vaz[2];
+    double kep_vaz[2], kep_vrad[2];
+    // bodies
+    int nbodies;
+    double bx[FCPT_MAX_BODIES], by[FCPT_MAX_BODIES], bm[FCPT_MAX_BODIES], brsm[FCPT_MAX_BODIES];
+    double indirect_x, indirect_y;
+};
+
+} // namespace fcpt
+
+#endif

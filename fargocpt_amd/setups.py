@@ -1,0 +1,129 @@
+"""Descriptor presets: the reference's YAML setups as fcpt_desc values.
+
+Each preset mirrors a setup file of the reference (cited), with the grid size
+left free.  All numbers are code units (G = M* = 1, L0 = 1 au).
+"""
+from __future__ import annotations
+
+from . import binding as B
+
+# code-unit conversion of the reference's default units (src/units.cpp:158-185)
+_G_CGS, _KB, _MU = 6.67430e-8, 1.380649e-16, 1.66053906660e-24
+_L0, _M0 = 1.495978707e13, 1.988409870698051e33
+TEMP0_K = _G_CGS * _MU / _KB * _M0 / _L0            # Kelvin per code temperature
+SIGMA_CGS = _M0 / (_L0 * _L0)                        # g/cm^2 per code surface density
+M_JUP = 9.547919e-4                                  # jupiterMass / solMass
+
+
+def _composite(d: B.Desc, side: int, name: str):
+    """InnerBoundary/OuterBoundary composites (src/boundary_conditions/config.cpp:345-440)."""
+    name = name.lower()
+    d.bc_sigma[side] = B.BC_ZEROGRADIENT
+    d.bc_energy[side] = B.BC_ZEROGRADIENT
+    d.bc_vrad[side] = {"zerogradient": B.BC_ZEROGRADIENT, "outflow": B.BC_OUTFLOW,
+                       "reflecting": B.BC_REFLECTING, "reference": B.BC_REFERENCE}[name]
+    if name == "reference":
+        d.bc_sigma[side] = d.bc_energy[side] = B.BC_REFERENCE
+    d.bc_vaz[side] = B.BC_KEPLERIAN  # default of InnerBoundaryVazi (config.cpp:263,305)
+
+
+def spreading_ring(lib: B.Library, nr=256, nphi=2) -> B.Desc:
+    """test/spreading_ring/setup.yml (viscous stress + transport, isothermal, constant nu)."""
+    d = lib.desc_default()
+    d.nr_global, d.nphi = nr, nphi
+    d.rmin, d.rmax, d.radial_spacing = 0.2, 1.8, B.SPACING_LOGARITHMIC
+    d.ic = B.IC_SPREADING_RING
+    d.sigma0 = 8.83829e+05 / SIGMA_CGS
+    d.sigma_slope, d.sigma_floor = 0.0, 1.0e-8
+    d.set_sigma0, d.disk_mass = 1, 1.0
+    d.aspect_ratio, d.flaring_index = 0.0, 0.0
+    d.constant_viscosity, d.viscous_alpha = 4.77e-5, 0.0
+    d.artificial_viscosity = B.ARTVISC_NONE
+    d.artificial_viscosity_dissipation = 0
+    d.eos, d.adiabatic_index = B.EOS_ISOTHERMAL, 1.0
+    d.heating_viscous = 0
+    d.minimum_temperature, d.maximum_temperature = 1e-9 / TEMP0_K, 1e100 / TEMP0_K
+    d.cfl, d.mu = 0.5, 1.0
+    d.initialize_vradial_zero = 1
+    d.thickness_smoothing = 0.0
+    d.fast_transport = 1
+    _composite(d, 0, "outflow")
+    _composite(d, 1, "outflow")
+    d.damping = 0
+    d.omega_frame = 0.0
+    d.nsnapshots, d.nmonitor, d.monitor_timestep = 1, 1, 314.159265359
+    d.damping_time_radius_outer = d.rmax
+    return d
+
+
+def shocktube(lib: B.Library, nr=100, nphi=2, artvisc="SN") -> B.Desc:
+    """test/shockTube/setups/shocktube_{SN,TW}.yml (Euler integrator variants)."""
+    d = lib.desc_default()
+    d.nr_global, d.nphi = nr, nphi
+    d.rmin, d.rmax, d.radial_spacing = 1000.0, 1001.0, B.SPACING_ARITHMETIC
+    d.ic = B.IC_SHOCKTUBE
+    d.sigma0 = 8887231.453904748 / SIGMA_CGS
+    d.sigma_slope, d.sigma_floor = 0.0, 1.0e-100
+    d.aspect_ratio, d.flaring_index = 1.0, 0.5
+    d.constant_viscosity, d.viscous_alpha = 0.0, 0.0
+    d.artificial_viscosity = {"SN": B.ARTVISC_SN, "TW": B.ARTVISC_TW}[artvisc]
+    d.artificial_viscosity_dissipation, d.artificial_viscosity_factor = 1, 1.41
+    d.eos, d.adiabatic_index = B.EOS_IDEAL, 1.4
+    d.heating_viscous = 1 if artvisc == "TW" else 0
+    # init_shock_tube_test sets every unit factor to 1 (src/init.cpp:443-516): Kelvin = code
+    d.minimum_temperature, d.maximum_temperature = 1e-9 / TEMP0_K, 1e100 / TEMP0_K
+    d.cfl, d.mu = 0.5, 1.0
+    d.thickness_smoothing = 0.6
+    d.fast_transport = 1
+    _composite(d, 0, "reflecting")
+    _composite(d, 1, "reflecting")
+    d.damping = 0
+    d.omega_frame = 0.0
+    d.nsnapshots, d.nmonitor, d.monitor_timestep = 1, 1, 0.228
+    d.G = d.Rgas = 1.0
+    d.damping_time_radius_outer = d.rmax
+    return d
+
+
+def planet_disk(lib: B.Library, nr=128, nphi=384, adiabatic=False, damping=True,
+                first_dt=1e-3) -> B.Desc:
+    """examples/config.yml: locally isothermal (or ideal) disk, alpha = 1e-3, TW artificial
+    viscosity, reflecting boundaries + wave damping, frame rotating with Omega = 1.
+    FirstDT = 1e-3 skips the 1.1x ramp from the default 1e-9."""
+    d = lib.desc_default()
+    d.nr_global, d.nphi = nr, nphi
+    d.rmin, d.rmax, d.radial_spacing = 0.4, 2.5, B.SPACING_LOGARITHMIC
+    d.ic = B.IC_PROFILE
+    d.sigma0 = 200.0 / SIGMA_CGS
+    d.sigma_slope, d.sigma_floor = 0.5, 1e-9
+    d.aspect_ratio, d.flaring_index = 0.05, 0.0
+    d.viscous_alpha, d.constant_viscosity = 1.0e-3, 0.0
+    d.artificial_viscosity = B.ARTVISC_TW
+    d.artificial_viscosity_dissipation, d.artificial_viscosity_factor = 1, 1.41
+    d.eos = B.EOS_IDEAL if adiabatic else B.EOS_ISOTHERMAL
+    d.adiabatic_index, d.mu = 1.4, 2.35
+    d.heating_viscous = 1
+    d.minimum_temperature, d.maximum_temperature = 3.0 / TEMP0_K, 1e100 / TEMP0_K
+    d.heating_cooling_cfl_limit = 1.0
+    d.cfl, d.cfl_max_var, d.first_dt = 0.5, 1.1, first_dt
+    d.thickness_smoothing = 0.6
+    d.fast_transport = 1
+    d.omega_frame = 1.0
+    _composite(d, 0, "reflecting")
+    _composite(d, 1, "reflecting")
+    d.damping = 1 if damping else 0
+    d.damping_inner_limit, d.damping_outer_limit = 1.10, 0.90
+    d.damping_time_factor, d.damping_time_radius_outer = 1.0e-1, 2.5
+    for arr in (d.damp_vrad, d.damp_vaz, d.damp_sigma, d.damp_energy):
+        arr[0] = arr[1] = B.DAMP_REFERENCE
+    d.nsnapshots, d.nmonitor, d.monitor_timestep = 50, 10, 0.628
+    return d
+
+
+def jupiter_bodies(d: B.Desc):
+    """Star + Jupiter of examples/config.yml for fcpt_set_bodies: the planet sits at
+    (1, 0) in the frame rotating with OmegaFrame = 1 (no indirect term, no feedback)."""
+    x = [0.0, 1.0]
+    y = [0.0, 0.0]
+    m = [d.hydro_center_mass, M_JUP]
+    return x, y, m

@@ -1,0 +1,333 @@
+/*
+ * fargocpt_hip.h -- C ABI of the MI355X-native FargoCPT gas update.
+ *
+ * The reference (kimweiskopf/fargocpt) has no FFI layer: its per-timestep gas
+ * update is a set of free C++ functions over global state, called from
+ * step_Euler (src/simulation.cpp:148-267).  This header is the boundary a
+ * maintainer would bind instead of those calls; every entry point names the
+ * reference function(s) it replaces.  Plain C types only: pointers, sizes,
+ * doubles, int32.  One context per GPU / radial slab, one host thread per
+ * context, all device work on one HIP stream (fcpt_set_stream).
+ *
+ * Field layout is the reference's t_polargrid::Field (src/polargrid.h:111-133):
+ * row-major double[nr*nphi + naz], phi contiguous.  Scalar grids have Nr rows,
+ * "vector" grids (v_radial, and tau_r_phi internally) have Nr+1 rows.
+ *
+ * All functions return 0 on success or a negative FCPT_E* code; no exceptions
+ * cross the ABI.  fcpt_last_error() gives a human-readable message.
+ */
+#ifndef FARGOCPT_HIP_H
+#define FARGOCPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCPT_ABI_VERSION 1
+
+/* error codes */
+#define FCPT_OK 0
+#define FCPT_EINVAL -1  /* bad argument / unsupported configuration */
+#define FCPT_ENOMEM -2  /* host or device allocation failed */
+#define FCPT_EHIP -3    /* a HIP runtime call failed */
+#define FCPT_ESPLIT -4  /* slab too narrow: needs >= 2*FCPT_OVERLAP rings (src/split.cpp:42-47) */
+#define FCPT_ENODEV -5  /* no HIP device */
+
+/* src/constants.h:17-19 */
+#define FCPT_OVERLAP 7
+#define FCPT_GHOSTCELLS_B 1
+/* rows of geometry kept past the last local ring (src/init.cpp:40-45 search_buffer) */
+#define FCPT_GEOM_PAD 15
+#define FCPT_MAX_BODIES 8
+
+/* enum-like int32 values of fcpt_desc ------------------------------------ */
+enum { FCPT_SPACING_ARITHMETIC = 0, FCPT_SPACING_LOGARITHMIC = 1, FCPT_SPACING_EXPONENTIAL = 2 };
+enum { FCPT_EOS_ISOTHERMAL = 0, FCPT_EOS_IDEAL = 1 };
+enum { FCPT_ARTVISC_NONE = 0, FCPT_ARTVISC_TW = 1, FCPT_ARTVISC_SN = 2 };
+enum { FCPT_LIMITER_VANLEER = 0, FCPT_LIMITER_MC = 1 };
+enum { FCPT_INTEGRATOR_EULER = 0, FCPT_INTEGRATOR_LEAPFROG = 1 };
+/* per-variable boundary conditions (src/boundary_conditions/config.cpp:97-343) */
+enum {
+    FCPT_BC_ZEROGRADIENT = 0,
+    FCPT_BC_REFERENCE = 1,
+    FCPT_BC_REFLECTING = 2, /* vrad only */
+    FCPT_BC_OUTFLOW = 3,    /* vrad only */
+    FCPT_BC_KEPLERIAN = 4,  /* vrad: keplerian_radial, vaz: keplerian_azimuthal */
+    FCPT_BC_ZEROSHEAR = 5,  /* vaz only */
+    FCPT_BC_NONE = 6
+};
+/* damping target (src/boundary_conditions/damping.cpp:152-178) */
+enum { FCPT_DAMP_NONE = 0, FCPT_DAMP_REFERENCE = 1, FCPT_DAMP_ZERO = 2, FCPT_DAMP_MEAN = 3 };
+/* initial condition generator (src/init.cpp:255-343) */
+enum { FCPT_IC_PROFILE = 0, FCPT_IC_SPREADING_RING = 1, FCPT_IC_SHOCKTUBE = 2 };
+
+/* grids addressable through upload / download / device_ptr
+ * (subset of t_data::t_polargrid_type, src/data.h:17-86) */
+enum {
+    FCPT_F_SIGMA = 0,
+    FCPT_F_VRAD = 1, /* (Nr+1) x Nphi */
+    FCPT_F_VAZI = 2,
+    FCPT_F_ENERGY = 3,
+    FCPT_F_PRESSURE = 4,
+    FCPT_F_SOUNDSPEED = 5,
+    FCPT_F_SCALE_HEIGHT = 6,
+    FCPT_F_VISCOSITY = 7,
+    FCPT_F_TEMPERATURE = 8,
+    FCPT_F_POTENTIAL = 9,
+    FCPT_F_SIGMA0 = 10,
+    FCPT_F_VRAD0 = 11, /* (Nr+1) x Nphi */
+    FCPT_F_VAZI0 = 12,
+    FCPT_F_ENERGY0 = 13,
+    FCPT_F_QPLUS = 14,
+    FCPT_F_QMINUS = 15,
+    FCPT_F_COUNT = 16
+};
+
+/*
+ * Everything the path reads from parameters::*, global.h and refframe:: in the
+ * reference.  All lengths/times/masses are in code units (G = 1 by default).
+ * The YAML key each member mirrors is given on the right
+ * (src/parameters.cpp:520-900, src/Interpret.cpp:73-700,
+ *  src/boundary_conditions/config.cpp, damping.cpp:185-271).
+ */
+typedef struct fcpt_desc {
+    uint32_t struct_size; /* = sizeof(fcpt_desc), ABI check */
+    uint32_t abi_version; /* = FCPT_ABI_VERSION */
+
+    /* grid + radial slab decomposition (src/split.cpp:34-88) */
+    int32_t nr_global; /* Nrad */
+    int32_t nphi;      /* Naz */
+    int32_t rank;      /* slab index, 0 = innermost */
+    int32_t nranks;    /* number of slabs */
+    int32_t radial_spacing; /* RadialSpacing */
+    int32_t _pad0;
+    double rmin, rmax;                   /* Rmin, Rmax */
+    double exponential_cell_size_factor; /* ExponentialCellSizeFactor */
+
+    /* equation of state */
+    int32_t eos; /* EquationOfState */
+    int32_t _pad1;
+    double adiabatic_index; /* AdiabaticIndex */
+    double mu;              /* mu */
+    double aspect_ratio;    /* AspectRatio */
+    double flaring_index;   /* FlaringIndex */
+    double minimum_temperature, maximum_temperature; /* code units */
+
+    /* disk profile / floors */
+    double sigma0;      /* Sigma0 (code units) */
+    double sigma_slope; /* SigmaSlope */
+    double sigma_floor; /* SigmaFloor (multiples of sigma0) */
+
+    /* viscosity */
+    double viscous_alpha;           /* ViscousAlpha */
+    double constant_viscosity;      /* ConstantViscosity */
+    double radial_viscosity_factor; /* RadialViscosityFactor */
+    int32_t stabilize_viscosity;    /* StabilizeViscosity: only 0 is supported */
+    int32_t artificial_viscosity;   /* ArtificialViscosity */
+    double artificial_viscosity_factor;       /* ArtificialViscosityFactor */
+    int32_t artificial_viscosity_dissipation; /* ArtificialViscosityDissipation */
+    int32_t heating_viscous;                  /* HeatingViscous */
+    double heating_viscous_factor;            /* HeatingViscousFactor */
+
+    /* transport */
+    int32_t fast_transport; /* Transport: FARGO=1 / standard=0 */
+    int32_t flux_limiter;   /* FluxLimiter */
+
+    /* time stepping */
+    int32_t integrator; /* Integrator */
+    int32_t _pad2;
+    double cfl;                       /* CFL */
+    double cfl_max_var;               /* CFLmaxVar */
+    double first_dt;                  /* FirstDT */
+    double heating_cooling_cfl_limit; /* HeatingCoolingCFLlimit */
+    double monitor_timestep;          /* MonitorTimestep */
+    int32_t nmonitor;                 /* Nmonitor */
+    int32_t nsnapshots;               /* Nsnapshots */
+
+    /* frame + gravity */
+    double omega_frame;                /* OmegaFrame */
+    double thickness_smoothing;        /* ThicknessSmoothing */
+    int32_t body_force_from_potential; /* BodyForceFromPotential: only 1 is supported */
+    int32_t _pad3;
+    double hydro_center_mass; /* mass of the bodies defining the hydro centre */
+
+    /* boundary conditions: [0] = inner, [1] = outer */
+    int32_t bc_sigma[2];
+    int32_t bc_energy[2];
+    int32_t bc_vrad[2];
+    int32_t bc_vaz[2];
+    double keplerian_vaz_factor[2];  /* Inner/OuterBoundaryVaziKeplerianFactor */
+    double keplerian_vrad_factor[2]; /* Inner/OuterBoundaryVradKeplerianFactor */
+
+    /* wave damping */
+    int32_t damping; /* Damping */
+    int32_t _pad4;
+    double damping_inner_limit;       /* DampingInnerLimit */
+    double damping_outer_limit;       /* DampingOuterLimit */
+    double damping_time_factor;       /* DampingTimeFactor */
+    double damping_time_radius_outer; /* DampingTimeRadiusOuter */
+    int32_t damp_vrad[2];   /* DampingVRadialInner/Outer */
+    int32_t damp_vaz[2];    /* DampingVAzimuthalInner/Outer */
+    int32_t damp_sigma[2];  /* DampingSurfaceDensityInner/Outer */
+    int32_t damp_energy[2]; /* DampingEnergyInner/Outer */
+
+    /* physical constants in code units (src/constants.cpp:236-262) */
+    double G, Rgas, sigma_sb, c_light;
+
+    /* initial conditions (src/init.cpp) */
+    int32_t ic;                      /* ShockTube / SpreadingRing / profile */
+    int32_t set_sigma0;              /* SetSigma0 */
+    double disk_mass;                /* DiskMass */
+    int32_t initialize_vradial_zero; /* InitializeVradialZero */
+    int32_t initialize_pure_keplerian; /* InitializePureKeplerian */
+} fcpt_desc;
+
+/* Row ranges of a slab, exactly the integers of src/split.cpp:56-78. */
+typedef struct fcpt_split {
+    int32_t nr;   /* local NRadial (overlap included) */
+    int32_t imin; /* IMIN: global index of local row 0 */
+    int32_t imax; /* IMAX */
+    int32_t zero_no_ghost;
+    int32_t one_no_ghost_vr;
+    int32_t max_no_ghost;
+    int32_t maxmo_no_ghost_vr;
+    int32_t zero_or_active;
+    int32_t max_or_active;
+    int32_t radial_first_active;
+    int32_t radial_active_size;
+    int32_t is_first; /* CPU_Rank == 0 */
+    int32_t is_last;  /* CPU_Rank == CPU_Highest */
+} fcpt_split;
+
+/* simulation clock, the state of namespace sim (src/simulation.cpp:24-31) */
+typedef struct fcpt_clock {
+    double time;
+    double last_dt;
+    uint64_t n_hydro_iter;
+    uint32_t n_monitor;
+    uint32_t n_snapshot;
+} fcpt_clock;
+
+typedef struct fcpt_ctx fcpt_ctx;
+
+/* ---- host-side helpers (no GPU needed) -------------------------------- */
+
+/* Fill a descriptor with the reference's defaults (src/parameters.cpp,
+ * src/Interpret.cpp).  Always succeeds. */
+int fcpt_desc_default(fcpt_desc *d);
+
+/* SplitDomain (src/split.cpp:34-88) for slab d->rank of d->nranks. */
+int fcpt_split_domain(const fcpt_desc *d, fcpt_split *out);
+
+/* Interface radii Radii[0 .. nr_global + FCPT_GEOM_PAD] of the global grid
+ * (src/init.cpp:92-145).  `radii` must hold nr_global + FCPT_GEOM_PAD + 1 doubles. */
+int fcpt_radii(const fcpt_desc *d, double *radii);
+
+/* Initial gas fields of slab d->rank (init_physics, src/init.cpp:255-343:
+ * init_gas_density / init_gas_energy / init_gas_velocities / shock tube /
+ * spreading ring) before the first boundary call.  With SetSigma0 the descriptor's
+ * sigma0 is rescaled in place, as parameters::sigma0 is (src/init.cpp:1155).
+ * Arrays are local-slab sized:
+ * sigma, vazi, energy: nr*nphi; vrad: (nr+1)*nphi.  energy may be NULL for
+ * isothermal runs. */
+int fcpt_initial_fields(fcpt_desc *d, const double *radii, double *sigma, double *vrad,
+                        double *vazi, double *energy);
+
+const char *fcpt_last_error(void);
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Allocate all device state for slab d->rank on the current HIP device.
+ * `radii` is the global interface array from fcpt_radii (or a radii.dat).
+ * Replaces data.set_size + init_radialarrays + InitTransport + cfl::init
+ * (src/main.cpp:96-103, src/TransportEuler.cpp:57-96, src/cfl.cpp:14-18). */
+int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out);
+int fcpt_destroy(fcpt_ctx *ctx);
+
+/* Launch all subsequent work of this context on `hip_stream` (a hipStream_t;
+ * NULL = the default stream).  Lets the caller order kernels against its own
+ * copies / RCCL calls without extra synchronisation. */
+int fcpt_set_stream(fcpt_ctx *ctx, void *hip_stream);
+int fcpt_synchronize(fcpt_ctx *ctx);
+
+int fcpt_get_split(const fcpt_ctx *ctx, fcpt_split *out);
+int fcpt_get_clock(const fcpt_ctx *ctx, fcpt_clock *out);
+int fcpt_set_clock(fcpt_ctx *ctx, const fcpt_clock *in);
+
+/* Host <-> device copies of one grid in the reference's Field layout
+ * (what read2D / write2D move, src/polargrid.cpp:135-180,301-353).
+ * Synchronous with respect to the context's stream. */
+int fcpt_upload(fcpt_ctx *ctx, int32_t field, const double *host);
+int fcpt_download(fcpt_ctx *ctx, int32_t field, double *host);
+/* Device address and element count of a grid, for zero-copy callers. */
+int fcpt_device_ptr(fcpt_ctx *ctx, int32_t field, void **dptr, uint64_t *count);
+
+/* Positions, masses and cubic smoothing radii of the N-body objects for the
+ * next potential evaluation, plus the indirect-term acceleration
+ * (CalculateNbodyPotential, src/Pframeforce.cpp:21-94).  Body 0 is the star. */
+int fcpt_set_bodies(fcpt_ctx *ctx, int32_t n, const double *x, const double *y, const double *mass,
+                    const double *cubic_smoothing_radius, double indirect_x, double indirect_y);
+
+/* After the initial Sigma/v/energy upload: init_euler (src/SourceEuler.cpp:251-285:
+ * sound speed, pressure, temperature, scale height, viscosity), the first
+ * potential, copy_initial_values + apply_boundary_condition + copy_initial_values
+ * (src/init.cpp:337-341). */
+int fcpt_init_physics(fcpt_ctx *ctx);
+
+/* ---- the hot path -------------------------------------------------------- */
+
+/* cfl::condition_cfl without the MPI_Allreduce (src/cfl.cpp:185-376): the
+ * minimum over this slab's active rings.  Blocks until the value is on the host. */
+int fcpt_cfl(fcpt_ctx *ctx, double *dt_local);
+
+/* sim::CalculateTimeStep's policy (src/simulation.cpp:100-118) applied to the
+ * globally reduced CFL dt: returns min(CFLmaxVar*last_dt, cfl_dt) and stores it
+ * as last_dt. */
+int fcpt_calculate_timestep(fcpt_ctx *ctx, double cfl_dt_global, double *dt);
+
+/* The monitor-time snapping of sim::run (src/simulation.cpp:528-540). */
+int fcpt_snap_to_monitor(const fcpt_ctx *ctx, double cfl_dt, double *step_dt);
+
+/* step_Euler up to and including Transport (src/simulation.cpp:167-217):
+ * potential, update_with_sourceterms, update_with_artificial_viscosity,
+ * recalculate_viscosity, compute_viscous_stress_tensor,
+ * update_velocities_with_viscosity, SubStep3, apply_boundary_condition(final=false),
+ * Transport.  Asynchronous on the context's stream.  Advances time by dt. */
+int fcpt_step(fcpt_ctx *ctx, double dt);
+
+/* CommunicateBoundaries, device side (src/commbound.cpp:108-125,163-180):
+ * pack rows [7,14) -> send_inner and rows [nr-14,nr-7) -> send_outer of
+ * Sigma, vrad, vazi(, energy); unpack recv_inner -> rows [0,7) and
+ * recv_outer -> rows [nr-7,nr).  Buffers are device pointers of
+ * fcpt_exchange_count() doubles each; a NULL pointer skips that side.  The
+ * transfer itself (RCCL send/recv between neighbouring slabs) is done by the
+ * caller on the same stream. */
+int fcpt_exchange_count(const fcpt_ctx *ctx, uint64_t *count);
+int fcpt_exchange_pack(fcpt_ctx *ctx, double *send_inner, double *send_outer);
+int fcpt_exchange_unpack(fcpt_ctx *ctx, const double *recv_inner, const double *recv_outer);
+
+/* The rest of step_Euler after CommunicateBoundaries (src/simulation.cpp:244-265):
+ * apply_boundary_condition(final=true) (damping first) and
+ * recalculate_derived_disk_quantities.  Asynchronous. */
+int fcpt_post(fcpt_ctx *ctx, double dt);
+
+/* boundary_conditions::apply_boundary_condition (src/boundary_conditions/boundary_conditions.cpp:65-114):
+ * wave damping first when `final` is non-zero, then the eight per-variable ghost-ring
+ * conditions.  Asynchronous.  (fcpt_step and fcpt_post call it internally; sim::init
+ * calls it once more before the loop, src/simulation.cpp:463.) */
+int fcpt_apply_boundary(fcpt_ctx *ctx, double dt, int32_t final);
+
+/* Convenience for single-slab runs: K iterations of
+ * {cfl, calculate_timestep, [snap], step, post} without returning to the caller,
+ * as sim::run does (src/simulation.cpp:515-553).  If `snap` is non-zero the
+ * step is snapped to monitor times and n_monitor advances.  nsteps_done may be
+ * NULL.  Stops early when time reaches t_final = nsnapshots*nmonitor*monitor_timestep
+ * unless t_final <= 0. */
+int fcpt_run_steps(fcpt_ctx *ctx, int64_t nsteps, int32_t snap, int64_t *nsteps_done);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FARGOCPT_HIP_H */
