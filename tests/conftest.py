@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+# The oracle is OpenMP code: pin its team size before libgomp starts, otherwise a box
+# that reports more processors than its CPU quota oversubscribes and crawls.
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, len(os.sched_getaffinity(0))))))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
