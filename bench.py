@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cell-updates/s of the per-timestep gas update on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full hydro step (CFL reduction, source + viscosity substeps, boundary
+rings, FARGO transport, ghost exchange, derived quantities) of the 2048 x 4096
+locally-isothermal disk + Jupiter-mass planet (examples/config.yml physics, BASELINE.json
+config 2 at the grid the metric is quoted on).  With N > 1 every rank owns 2048 rings
+(weak scaling; the log grid is extended outward so dr/r stays constant) and neighbours
+exchange 7 ghost rings per step over RCCL.
+
+Prints one JSON line on rank 0 (see the driver contract).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NR_PER_GPU, NPHI = 2048, 4096
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# Algorithmic (minimum distinct read + written) doubles per cell of each kernel, isothermal /
+# adiabatic; derivation in DESIGN.md section "Kernels".  SURVEY.md section 8(d)'s pass model:
+# A source+viscosity 5|7, B radial transport 8|10, C azimuthal transport 11|13,
+# D velocities+floors+CFL 8|10 => 32|40 doubles = 256|320 B per cell-update.
+ALGO_DOUBLES = {
+    "k_transport_radial": (8, 10),   # read Sigma,vr,vphi(,e) -> write rm+-,L+-,Sigma(,e)
+    "k_transport_theta1": (11, 13),  # read 5(6) + vphi -> write 5(6)
+    "k_transport_theta2": (10, 12),  # read 5(6) -> write 5(6) (shifted)
+    "k_velocities": (8, 10),         # read 5(6) -> write vr,vphi,Sigma(,e)
+    "k_source_vr": (6, 6), "k_source_va": (4, 4), "k_tw_q": (5, 6), "k_tw_va": (3, 3),
+    "k_tw_vr": (4, 4), "k_stress_diag": (7, 7), "k_stress_rphi": (5, 5), "k_visc_va": (4, 4),
+    "k_visc_vr": (5, 5), "k_cfl_cells": (4, 7), "k_pressure": (3, 2), "k_potential": (2, 2),
+    "k_ring_mean": (1, 1),
+}
+STEP_BYTES = (256, 320)
+
+
+def affinity_threads(cap=16):
+    return max(1, min(cap, len(os.sched_getaffinity(0))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nr", type=int, default=NR_PER_GPU, help="rings per GPU")
+    ap.add_argument("--nphi", type=int, default=NPHI)
+    args = ap.parse_args()
+
+    os.environ.setdefault("OMP_NUM_THREADS", str(affinity_threads()))
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+    import numpy as np
+    import torch  # first: the HIP runtime torch bundles must be the one the library binds to
+    import torch.distributed as dist
+
+    import fargocpt_amd
+    from fargocpt_amd import binding as B, driver, setups
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    lib = fargocpt_amd.load()
+    nr_global = args.nr * world
+    d = setups.planet_disk(lib, nr_global, args.nphi)
+    if world > 1:
+        # weak scaling: keep dr/r of the 1-GPU grid, extend the disk outward
+        d.rmax = d.rmin * (2.5 / 0.4) ** world
+        d.damping_time_radius_outer = d.rmax
+    d.rank, d.nranks = rank, world
+    bodies = setups.jupiter_bodies(d)
+
+    radii = lib.radii(d)
+    fields = lib.initial_fields(d.copy(), radii)  # slab-local
+    ctx = driver.make_context(lib, d, fields=fields, radii=radii, bodies=bodies)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    adi = 1 if d.eos == B.EOS_IDEAL else 0
+
+    # ---- one step ------------------------------------------------------------
+    if world == 1:
+        def run(n):
+            ctx.run_steps(n, snap=False)  # dt stays on the device, no host sync inside
+    else:
+        cnt = ctx.exchange_count()
+        s_in, s_out, r_in, r_out = (torch.empty(cnt, dtype=torch.float64, device=dev) for _ in range(4))
+        dt_t = torch.empty(1, dtype=torch.float64, device=dev)
+        has_in, has_out = rank > 0, rank < world - 1
+
+        def exchange():
+            ctx.exchange_pack(s_in.data_ptr() if has_in else None, s_out.data_ptr() if has_out else None)
+            ops = []
+            if has_in:
+                ops += [dist.P2POp(dist.isend, s_in, rank - 1), dist.P2POp(dist.irecv, r_in, rank - 1)]
+            if has_out:
+                ops += [dist.P2POp(dist.isend, s_out, rank + 1), dist.P2POp(dist.irecv, r_out, rank + 1)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            ctx.exchange_unpack(r_in.data_ptr() if has_in else None, r_out.data_ptr() if has_out else None)
+
+        def run(n):
+            for _ in range(n):
+                dt_t[0] = ctx.cfl()
+                dist.all_reduce(dt_t, op=dist.ReduceOp.MIN)  # cfl.cpp:379
+                dt = ctx.calculate_timestep(float(dt_t.item()))
+                ctx.step(dt)
+                exchange()  # commbound.cpp:98-182
+                ctx.post(dt)
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    # sim::init's pre-loop time-step calls (main.cpp:117, simulation.cpp:466-468)
+    if world == 1:
+        for _ in range(2):
+            ctx.calculate_timestep(ctx.cfl())
+    else:
+        for _ in range(2):
+            dt_t[0] = ctx.cfl()
+            dist.all_reduce(dt_t, op=dist.ReduceOp.MIN)
+            ctx.calculate_timestep(float(dt_t.item()))
+
+    # ---- warm-up, with a per-kernel calibration pass to find the dominant kernel --
+    cal = min(3, max(1, args.warmup))
+    ctx.profile_start(None, max_launches=64 * cal)
+    run(cal)
+    prof = ctx.profile_stop()
+    dominant = max(prof, key=lambda k: prof[k][0])
+    names = lib.kernel_names()
+    if args.warmup > cal:
+        run(args.warmup - cal)
+
+    # ---- timed region ---------------------------------------------------------
+    ctx.profile_start([names.index(dominant)], max_launches=args.steps + 8)
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run(args.steps)
+    sync()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    dom = ctx.profile_stop()[dominant]
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = ctx.state()
+    finite = all(np.isfinite(v).all() for v in st.values())
+
+    if rank == 0:
+        cells = nr_global * args.nphi
+        value = cells * args.steps / elapsed
+        dom_ms = dom[0] / max(1, dom[1])
+        slab_cells = ctx.nr * args.nphi
+        algo_bytes = ALGO_DOUBLES.get(dominant, (0, 0))[adi] * 8 * slab_cells
+        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("workload") == f"{args.nr}x{args.nphi}":
+                    traffic = rec.get("hbm_bytes_per_launch", {}).get(dominant)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "cell-updates/s on Nr x Nphi polar grid", "value": value, "unit": "cell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{nr_global}x{args.nphi} locally-isothermal disk + 1 Jupiter-mass planet "
+                                   "(examples/config.yml physics: alpha=1e-3, TW artificial viscosity, "
+                                   "reflecting BC + damping, FARGO transport, Euler), "
+                                   f"{args.nr} rings per GPU",
+                       "grid": [nr_global, args.nphi], "parallelism": f"radial slabs x{world}",
+                       "finite": bool(finite)},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": dom_ms, "launches": dom[1],
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "step_frac": value * STEP_BYTES[adi] / (HBM_PEAK_GBS * 1e9 * world)},
+            "kernel_ms_per_step": {k: v[0] / cal for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(lib, d, fields, radii, bodies)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(lib, d, fields, radii, bodies):
+    """The CPU oracle (oracle/fargo_oracle.c, a C+OpenMP restatement of the reference loops)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    import ctypes
+    import subprocess
+    from fargocpt_amd import binding as B, driver
+
+    so = os.path.join(ROOT, "oracle", "libfargo_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    orc = B.Library(ctypes.CDLL(so), "orc_")
+    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    ctx = driver.make_context(orc, d, fields=fields, radii=radii, bodies=bodies)
+    for _ in range(2):
+        ctx.calculate_timestep(ctx.cfl())
+    ctx.run_steps(1)  # page in
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        ctx.run_steps(1)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or n >= 40:
+            break
+    cells = d.nr_global * d.nphi
+    ctx.close()
+    return {"value": cells * n / el, "unit": "cell-updates/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of the same {d.nr_global}x{d.nphi} workload, oracle/fargo_oracle.c "
+                      f"(-O2, OpenMP, {threads} threads)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -152,6 +152,12 @@ class Library:
                                              _as_dp(vazi), _as_dp(energy)), "initial_fields")
         return sigma, vrad, vazi, energy
 
+    def kernel_names(self):
+        n = self.fn("kernel_count")()
+        f = self.fn("kernel_name")
+        f.restype = C.c_char_p
+        return [f(_i32(k)).decode() for k in range(n)]
+
     def create(self, d: Desc, radii: np.ndarray) -> "Context":
         return Context(self, d, radii)
 
@@ -258,6 +264,18 @@ class Context:
         if isinstance(b, np.ndarray):
             return _as_dp(b)
         return C.cast(C.c_void_p(int(b)), _dp)
+
+    def profile_start(self, kernel_ids=None, max_launches: int = 4096):
+        mask = (1 << 64) - 1 if kernel_ids is None else sum(1 << k for k in kernel_ids)
+        self._call("profile_start", _u64(mask), _i32(max_launches))
+
+    def profile_stop(self):
+        """-> {kernel name: (total ms, launches)} for the kernels that ran."""
+        names = self.lib.kernel_names()
+        ms = (_f64 * len(names))()
+        cnt = (C.c_int64 * len(names))()
+        self._call("profile_stop", ms, cnt)
+        return {n: (ms[k], cnt[k]) for k, n in enumerate(names) if cnt[k] > 0}
 
     def run_steps(self, nsteps: int, snap: bool = False) -> int:
         done = C.c_int64()

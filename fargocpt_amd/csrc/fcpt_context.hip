@@ -33,9 +33,17 @@ struct fcpt_ctx {
     DampRange damp[4][2]; // [vrad, vaz, sigma, energy][inner, outer]
     bool potential_valid = false;
     DevClock *h_clk = nullptr; // pinned staging copy
+    Profiler prof;
+    bool profiling = false;
 };
 
 namespace {
+
+// routes this thread's launches to the context's profiler while it is recording
+struct ProfScope {
+    explicit ProfScope(fcpt_ctx *c) { g_prof = c->profiling ? &c->prof : nullptr; }
+    ~ProfScope() { g_prof = nullptr; }
+};
 
 template <class T> int dev_alloc(fcpt_ctx *c, T **p, size_t n)
 {
@@ -374,6 +382,8 @@ int fcpt_destroy(fcpt_ctx *c)
         (void)hipFree(p);
     if (c->h_clk)
         (void)hipHostFree(c->h_clk);
+    for (hipEvent_t e : c->prof.events)
+        (void)hipEventDestroy(e);
     delete c;
     return FCPT_OK;
 }
@@ -502,6 +512,7 @@ int fcpt_init_physics(fcpt_ctx *c)
 {
     if (!c)
         return FCPT_EINVAL;
+    ProfScope prof_scope(c);
     const Dev &P = c->P;
     hipStream_t st = c->stream;
     if (!P.adiabatic) {
@@ -534,6 +545,7 @@ int fcpt_cfl(fcpt_ctx *c, double *dt_local)
 {
     if (!c || !dt_local)
         return FCPT_EINVAL;
+    ProfScope prof_scope(c);
     launch_cfl(c->P, c->stream);
     HIPCHK(hipGetLastError());
     DevClock k;
@@ -579,6 +591,7 @@ int fcpt_step(fcpt_ctx *c, double dt)
 {
     if (!c)
         return FCPT_EINVAL;
+    ProfScope prof_scope(c);
     launch_clock_set_dt(c->P.clk, dt, c->stream);
     enqueue_step(c);
     HIPCHK(hipGetLastError());
@@ -589,6 +602,7 @@ int fcpt_post(fcpt_ctx *c, double dt)
 {
     if (!c)
         return FCPT_EINVAL;
+    ProfScope prof_scope(c);
     launch_clock_set_dt(c->P.clk, dt, c->stream);
     enqueue_post(c);
     HIPCHK(hipGetLastError());
@@ -599,6 +613,7 @@ int fcpt_apply_boundary(fcpt_ctx *c, double dt, int32_t final)
 {
     if (!c)
         return FCPT_EINVAL;
+    ProfScope prof_scope(c);
     launch_clock_set_dt(c->P.clk, dt, c->stream);
     apply_boundary(c, final != 0);
     HIPCHK(hipGetLastError());
@@ -651,11 +666,53 @@ int fcpt_exchange_unpack(fcpt_ctx *c, const double *recv_inner, const double *re
     return FCPT_OK;
 }
 
+int32_t fcpt_kernel_count(void) { return KID_COUNT; }
+const char *fcpt_kernel_name(int32_t id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
+
+int fcpt_profile_start(fcpt_ctx *c, uint64_t mask, int32_t max_launches)
+{
+    if (!c || max_launches < 0)
+        return FCPT_EINVAL;
+    Profiler &p = c->prof;
+    while ((int)p.events.size() < 2 * max_launches) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        p.events.push_back(e);
+    }
+    p.mask = mask;
+    p.used = 0;
+    p.open_id = -1;
+    p.ids.clear();
+    c->profiling = true;
+    return FCPT_OK;
+}
+
+int fcpt_profile_stop(fcpt_ctx *c, double *ms_total, int64_t *launches)
+{
+    if (!c || !ms_total || !launches)
+        return FCPT_EINVAL;
+    c->profiling = false;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < KID_COUNT; ++k) {
+        ms_total[k] = 0.0;
+        launches[k] = 0;
+    }
+    Profiler &p = c->prof;
+    for (size_t n = 0; n < p.ids.size(); ++n) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, p.events[2 * n], p.events[2 * n + 1]));
+        ms_total[p.ids[n]] += ms;
+        launches[p.ids[n]] += 1;
+    }
+    return FCPT_OK;
+}
+
 // sim::run's loop (simulation.cpp:515-553) for a single slab.
 int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
 {
     if (!c)
         return FCPT_EINVAL;
+    ProfScope prof_scope(c);
     int64_t n = 0;
     if (!snap) {
         // dt never leaves the device: CFL reduction -> policy kernel -> step -> post

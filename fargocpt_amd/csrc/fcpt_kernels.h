@@ -8,6 +8,28 @@
 
 namespace fcpt {
 
+enum KernelId {
+    KID_POTENTIAL, KID_SOURCE_VR, KID_SOURCE_VA, KID_COMPRESSION, KID_TW_Q, KID_TW_VA, KID_TW_VR,
+    KID_SN_Q, KID_SN_E, KID_SN_VR, KID_SN_VA, KID_TRANGE, KID_ADI_CS_H, KID_ISO_CS_H,
+    KID_VISCOSITY, KID_PRESSURE, KID_TEMPERATURE, KID_STRESS_DIAG, KID_STRESS_RPHI, KID_VISC_VA,
+    KID_VISC_VR, KID_QPLUS, KID_SUBSTEP3, KID_BOUNDARY, KID_DAMPING, KID_TRANSPORT_RADIAL,
+    KID_RING_MEAN, KID_THETA1, KID_THETA2, KID_VELOCITIES, KID_CFL_INIT, KID_CFL_CELLS, KID_CLOCK,
+    KID_COUNT
+};
+extern const char *const kKernelNames[KID_COUNT];
+
+// HIP-event stopwatch around selected kernel launches (on the launch stream).
+struct Profiler {
+    unsigned long long mask = 0;
+    std::vector<hipEvent_t> events;
+    std::vector<int> ids;
+    int used = 0;
+    int open_id = -1;
+    void begin(int id, hipStream_t st);
+    void end(int id, hipStream_t st);
+};
+extern thread_local Profiler *g_prof;
+
 void launch_potential(const Dev &P, hipStream_t st);
 void launch_source(const Dev &P, hipStream_t st);
 void launch_artificial_viscosity(const Dev &P, hipStream_t st);

@@ -884,71 +884,110 @@ __global__ void k_clock_policy(DevClock *clk, double cfl_max_var, int use_device
     clk->dt = rv;
 }
 
+
+// ---------------------------------------------------------------------------
+// per-kernel HIP-event timing (fcpt_profile_start/stop)
+const char *const kKernelNames[KID_COUNT] = {
+    "k_potential", "k_source_vr", "k_source_va", "k_compression_heating", "k_tw_q", "k_tw_va", "k_tw_vr",
+    "k_sn_q", "k_sn_e", "k_sn_vr", "k_sn_va", "k_temperature_range", "k_adi_cs_h", "k_iso_cs_h",
+    "k_viscosity", "k_pressure", "k_temperature", "k_stress_diag", "k_stress_rphi", "k_visc_va",
+    "k_visc_vr", "k_qplus_qminus", "k_substep3", "k_boundary", "k_damping", "k_transport_radial",
+    "k_ring_mean", "k_transport_theta1", "k_transport_theta2", "k_velocities", "k_cfl_init",
+    "k_cfl_cells", "k_clock"};
+
+thread_local Profiler *g_prof = nullptr;
+
+void Profiler::begin(int id, hipStream_t st)
+{
+    if (!((mask >> id) & 1ull) || used + 2 > (int)events.size())
+        return;
+    (void)hipEventRecord(events[used], st);
+    open_id = id;
+}
+void Profiler::end(int id, hipStream_t st)
+{
+    if (open_id != id)
+        return;
+    (void)hipEventRecord(events[used + 1], st);
+    ids.push_back(id);
+    used += 2;
+    open_id = -1;
+}
+
+#define KLAUNCH(id, kernel, grid, block, ...)                              \
+    do {                                                                   \
+        if (g_prof)                                                        \
+            g_prof->begin((id), st);                                       \
+        hipLaunchKernelGGL(kernel, (grid), (block), 0, st, __VA_ARGS__);   \
+        if (g_prof)                                                        \
+            g_prof->end((id), st);                                         \
+    } while (0)
+
 // ---------------------------------------------------------------------------
 // launchers
-#define LAUNCH2D(kernel, nrows, ...)                                                 \
+#define LAUNCH2D(id, kernel, nrows, ...)                                             \
     do {                                                                             \
         if ((nrows) > 0) {                                                           \
             const Launch2D l = launch2d((nrows), P.nphi);                            \
-            hipLaunchKernelGGL(kernel, l.grid, l.block, 0, st, __VA_ARGS__);         \
+            KLAUNCH(id, kernel, l.grid, l.block, __VA_ARGS__);                       \
         }                                                                            \
     } while (0)
 
-void launch_potential(const Dev &P, hipStream_t st) { LAUNCH2D(k_potential, P.nr, P); }
+void launch_potential(const Dev &P, hipStream_t st) { LAUNCH2D(KID_POTENTIAL, k_potential, P.nr, P); }
 
 void launch_source(const Dev &P, hipStream_t st)
 {
     // update_with_sourceterms, SourceEuler.cpp:435-452
-    LAUNCH2D(k_source_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
-    LAUNCH2D(k_source_va, P.max_no_ghost - P.zero_no_ghost, P);
+    LAUNCH2D(KID_SOURCE_VR, k_source_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
+    LAUNCH2D(KID_SOURCE_VA, k_source_va, P.max_no_ghost - P.zero_no_ghost, P);
     if (P.adiabatic)
-        LAUNCH2D(k_compression_heating, P.nr - 1, P);
+        LAUNCH2D(KID_COMPRESSION, k_compression_heating, P.nr - 1, P);
 }
 
 void launch_artificial_viscosity(const Dev &P, hipStream_t st)
 {
     // art_visc::update_with_artificial_viscosity, artificial_viscosity.cpp:11-26
     if (P.art_visc == FCPT_ARTVISC_TW) {
-        LAUNCH2D(k_tw_q, P.nr, P);
-        LAUNCH2D(k_tw_va, P.nr - 2, P);
-        LAUNCH2D(k_tw_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
+        LAUNCH2D(KID_TW_Q, k_tw_q, P.nr, P);
+        LAUNCH2D(KID_TW_VA, k_tw_va, P.nr - 2, P);
+        LAUNCH2D(KID_TW_VR, k_tw_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
     } else if (P.art_visc == FCPT_ARTVISC_SN) {
-        LAUNCH2D(k_sn_q, P.nr, P);
+        LAUNCH2D(KID_SN_Q, k_sn_q, P.nr, P);
         if (P.adiabatic && P.art_visc_dissipation)
-            LAUNCH2D(k_sn_e, P.max_no_ghost - P.zero_no_ghost, P);
-        LAUNCH2D(k_sn_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
-        LAUNCH2D(k_sn_va, P.max_no_ghost - P.zero_no_ghost, P);
+            LAUNCH2D(KID_SN_E, k_sn_e, P.max_no_ghost - P.zero_no_ghost, P);
+        LAUNCH2D(KID_SN_VR, k_sn_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
+        LAUNCH2D(KID_SN_VA, k_sn_va, P.max_no_ghost - P.zero_no_ghost, P);
     }
     if (P.adiabatic && P.art_visc_dissipation)
-        LAUNCH2D(k_temperature_range, P.nr, P);
+        LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
 }
 
 void launch_recalculate_viscosity(const Dev &P, hipStream_t st)
 {
     // recalculate_viscosity, SourceEuler.cpp:205-223 (AspectRatioMode 0)
     if (P.adiabatic)
-        LAUNCH2D(k_adi_cs_h, P.nr, P);
+        LAUNCH2D(KID_ADI_CS_H, k_adi_cs_h, P.nr, P);
     if (P.alpha_viscosity && P.adiabatic)
-        LAUNCH2D(k_viscosity, P.nr, P); // isothermal alpha-nu never changes after init
+        LAUNCH2D(KID_VISCOSITY, k_viscosity, P.nr, P); // isothermal alpha-nu never changes after init
 }
 
-void launch_viscosity_field(const Dev &P, hipStream_t st) { LAUNCH2D(k_viscosity, P.nr, P); }
+void launch_viscosity_field(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISCOSITY, k_viscosity, P.nr, P); }
 
 void launch_iso_cs_h(const Dev &P, const double *cs_ring, hipStream_t st)
 {
-    LAUNCH2D(k_iso_cs_h, P.nr, P, cs_ring);
+    LAUNCH2D(KID_ISO_CS_H, k_iso_cs_h, P.nr, P, cs_ring);
 }
 
 void launch_stress(const Dev &P, hipStream_t st)
 {
-    LAUNCH2D(k_stress_diag, P.nr, P);
-    LAUNCH2D(k_stress_rphi, P.nr - 1, P);
+    LAUNCH2D(KID_STRESS_DIAG, k_stress_diag, P.nr, P);
+    LAUNCH2D(KID_STRESS_RPHI, k_stress_rphi, P.nr - 1, P);
 }
 
 void launch_viscous_update(const Dev &P, hipStream_t st)
 {
-    LAUNCH2D(k_visc_va, P.nr - 2, P);
-    LAUNCH2D(k_visc_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
+    LAUNCH2D(KID_VISC_VA, k_visc_va, P.nr - 2, P);
+    LAUNCH2D(KID_VISC_VR, k_visc_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
 }
 
 void launch_substep3(const Dev &P, int update_energy, hipStream_t st)
@@ -956,17 +995,17 @@ void launch_substep3(const Dev &P, int update_energy, hipStream_t st)
     // SubStep3, SourceEuler.cpp:956-1051 (update_energy = 1) or the Q+/Q- part of
     // compute_heating_cooling_for_CFL, :1507-1547 (update_energy = 0)
     if (update_energy)
-        LAUNCH2D(k_temperature, P.nr, P);
-    LAUNCH2D(k_qplus_qminus, P.nr, P);
-    LAUNCH2D(k_substep3, P.nr - 2, P, update_energy);
+        LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P);
+    LAUNCH2D(KID_QPLUS, k_qplus_qminus, P.nr, P);
+    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr - 2, P, update_energy);
     if (update_energy)
-        LAUNCH2D(k_temperature_range, P.nr, P);
+        LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
 }
 
 void launch_boundary(const Dev &P, hipStream_t st)
 {
     const int bs = 256;
-    hipLaunchKernelGGL(k_boundary, dim3((P.nphi + bs - 1) / bs), dim3(bs), 0, st, P);
+    KLAUNCH(KID_BOUNDARY, k_boundary, dim3((P.nphi + bs - 1) / bs), dim3(bs), P);
 }
 
 void launch_damping(const Dev &P, double *q, double *q0, const double *radius, const DampRange &r,
@@ -974,64 +1013,64 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
 {
     if (r.type == FCPT_DAMP_NONE || r.lo > r.hi)
         return;
-    hipLaunchKernelGGL(k_damping, dim3(r.hi - r.lo + 1), dim3(256), 0, st, P, q, q0, radius, r.lo, r.type,
-                       r.rlim, r.redge, r.tau, is_density);
+    KLAUNCH(KID_DAMPING, k_damping, dim3(r.hi - r.lo + 1), dim3(256), P, q, q0, radius, r.lo, r.type, r.rlim,
+            r.redge, r.tau, is_density);
 }
 
 void launch_transport(const Dev &P, hipStream_t st)
 {
     // Transport, TransportEuler.cpp:112-136
-    LAUNCH2D(k_transport_radial, P.nr, P);
-    hipLaunchKernelGGL(k_ring_mean, dim3(P.nr), dim3(256), 0, st, P, 1);
+    LAUNCH2D(KID_TRANSPORT_RADIAL, k_transport_radial, P.nr, P);
+    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(256), P, 1);
     ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     ThetaOut outA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
     ThetaSet inA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
     ThetaOut outB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
-    LAUNCH2D(k_transport_theta<1>, P.nr, P, inB, outA);
-    LAUNCH2D(k_transport_theta<2>, P.nr, P, inA, outB);
-    LAUNCH2D(k_velocities, P.nr, P);
+    LAUNCH2D(KID_THETA1, k_transport_theta<1>, P.nr, P, inB, outA);
+    LAUNCH2D(KID_THETA2, k_transport_theta<2>, P.nr, P, inA, outB);
+    LAUNCH2D(KID_VELOCITIES, k_velocities, P.nr, P);
 }
 
 void launch_derived(const Dev &P, hipStream_t st)
 {
     // recalculate_derived_disk_quantities, SourceEuler.cpp:225-249 (AspectRatioMode 0)
     if (P.adiabatic) {
-        LAUNCH2D(k_temperature, P.nr, P);
-        LAUNCH2D(k_adi_cs_h, P.nr, P);
-        LAUNCH2D(k_pressure, P.nr, P);
+        LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P);
+        LAUNCH2D(KID_ADI_CS_H, k_adi_cs_h, P.nr, P);
+        LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P);
         if (P.alpha_viscosity)
-            LAUNCH2D(k_viscosity, P.nr, P);
+            LAUNCH2D(KID_VISCOSITY, k_viscosity, P.nr, P);
     } else {
-        LAUNCH2D(k_pressure, P.nr, P);
+        LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P);
     }
 }
 
-void launch_pressure(const Dev &P, hipStream_t st) { LAUNCH2D(k_pressure, P.nr, P); }
-void launch_temperature(const Dev &P, hipStream_t st) { LAUNCH2D(k_temperature, P.nr, P); }
+void launch_pressure(const Dev &P, hipStream_t st) { LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P); }
+void launch_temperature(const Dev &P, hipStream_t st) { LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P); }
 
 void launch_cfl(const Dev &P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_ring_mean, dim3(P.nr), dim3(256), 0, st, P, 0);
-    hipLaunchKernelGGL(k_cfl_init, dim3(1), dim3(1), 0, st, P);
+    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(256), P, 0);
+    KLAUNCH(KID_CFL_INIT, k_cfl_init, dim3(1), dim3(1), P);
     const int nrows = P.active_size - P.first_active;
     if (nrows > 0) {
         const Launch2D l = launch2d(nrows, P.nphi);
-        hipLaunchKernelGGL(k_cfl_cells, l.grid, l.block, 0, st, P);
+        KLAUNCH(KID_CFL_CELLS, k_cfl_cells, l.grid, l.block, P);
     }
 }
 
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_clock_set_dt, dim3(1), dim3(1), 0, st, clk, dt);
+    KLAUNCH(KID_CLOCK, k_clock_set_dt, dim3(1), dim3(1), clk, dt);
 }
 void launch_clock_advance(DevClock *clk, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_clock_advance, dim3(1), dim3(1), 0, st, clk);
+    KLAUNCH(KID_CLOCK, k_clock_advance, dim3(1), dim3(1), clk);
 }
 void launch_clock_policy(DevClock *clk, double cfl_max_var, int use_device_cfl, double cfl_global,
                          hipStream_t st)
 {
-    hipLaunchKernelGGL(k_clock_policy, dim3(1), dim3(1), 0, st, clk, cfl_max_var, use_device_cfl, cfl_global);
+    KLAUNCH(KID_CLOCK, k_clock_policy, dim3(1), dim3(1), clk, cfl_max_var, use_device_cfl, cfl_global);
 }
 
 } // namespace fcpt

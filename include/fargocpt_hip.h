@@ -327,6 +327,19 @@ int fcpt_apply_boundary(fcpt_ctx *ctx, double dt, int32_t final);
  * unless t_final <= 0. */
 int fcpt_run_steps(fcpt_ctx *ctx, int64_t nsteps, int32_t snap, int64_t *nsteps_done);
 
+/* ---- measurement ----------------------------------------------------------- */
+
+/* Per-kernel timing with HIP events recorded on the context's stream around each
+ * launch of the kernels selected by `mask` (bit k = kernel id k, see
+ * fcpt_kernel_name).  At most max_launches launches are recorded between start and
+ * stop.  fcpt_profile_stop synchronises and fills ms_total[id] / launches[id]
+ * (arrays of fcpt_kernel_count() entries).  Replaces nothing in the reference (its
+ * only timer is the wall clock of hydro_dt_logger, src/hydro_dt_logger.h:13-34). */
+int32_t fcpt_kernel_count(void);
+const char *fcpt_kernel_name(int32_t id);
+int fcpt_profile_start(fcpt_ctx *ctx, uint64_t mask, int32_t max_launches);
+int fcpt_profile_stop(fcpt_ctx *ctx, double *ms_total, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif
