@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -35,6 +36,7 @@ struct fcpt_ctx {
     DevClock *h_clk = nullptr; // pinned staging copy
     Profiler prof;
     bool profiling = false;
+    bool fused_source = true;
 };
 
 namespace {
@@ -122,9 +124,8 @@ DampRange damp_range(const fcpt_ctx *c, int is_vector, int type, int outer)
 }
 
 // boundary_conditions.cpp:65-114
-void apply_boundary(fcpt_ctx *c, bool final)
+void apply_boundary_view(fcpt_ctx *c, const Dev &P, bool final)
 {
-    const Dev &P = c->P;
     if (final && c->d.damping) {
         // damping.cpp:754-774, order of damping_vector: vrad, vaz, sigma, energy
         for (int o = 0; o < 2; ++o)
@@ -139,6 +140,7 @@ void apply_boundary(fcpt_ctx *c, bool final)
     }
     launch_boundary(P, c->stream);
 }
+void apply_boundary(fcpt_ctx *c, bool final) { apply_boundary_view(c, c->P, final); }
 
 int copy_initial_values(fcpt_ctx *c)
 {
@@ -168,15 +170,28 @@ void enqueue_step(fcpt_ctx *c)
         launch_potential(P, st); // CalculateNbodyPotential; static when H and the bodies are
         c->potential_valid = true;
     }
-    launch_source(P, st);
-    launch_artificial_viscosity(P, st);
-    launch_recalculate_viscosity(P, st);
-    launch_stress(P, st);
-    launch_viscous_update(P, st);
-    if (P.adiabatic)
-        launch_substep3(P, 1, st);
-    apply_boundary(c, false);
-    launch_transport(P, st);
+    if (c->fused_source) {
+        launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
+        launch_recalculate_viscosity(P, st);
+        launch_viscous_fused(P, st);         // (v) -> (v_b)
+        if (P.adiabatic)
+            launch_substep3_after_fused(P, st);
+        Dev Q = P; // view with the post-source velocities
+        Q.vrad = P.vrad_b;
+        Q.vazi = P.vazi_b;
+        apply_boundary_view(c, Q, false);
+        launch_transport(Q, P, st);
+    } else {
+        launch_source(P, st);
+        launch_artificial_viscosity(P, st);
+        launch_recalculate_viscosity(P, st);
+        launch_stress(P, st);
+        launch_viscous_update(P, st);
+        if (P.adiabatic)
+            launch_substep3(P, 1, st);
+        apply_boundary(c, false);
+        launch_transport(P, P, st);
+    }
     launch_clock_advance(P.clk, st);
 }
 
@@ -211,6 +226,10 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     }
     if (d->integrator != FCPT_INTEGRATOR_EULER) {
         set_error("Integrator: Leapfrog is not supported yet");
+        return FCPT_EINVAL;
+    }
+    if ((long long)(d->nr_global + 1) * (long long)d->nphi >= (1ll << 31)) {
+        set_error("grid too large for 32-bit cell indices");
         return FCPT_EINVAL;
     }
     int ndev = 0;
@@ -266,7 +285,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
 #define AL(field, n) \
     if (!rc)         \
         rc = dev_alloc(c, &P.field, (n));
-    AL(sigma, ns) AL(vrad, nv) AL(vazi, ns) AL(energy, ns)
+    AL(sigma, ns) AL(vrad, nv) AL(vazi, ns) AL(energy, ns) AL(vrad_b, nv) AL(vazi_b, ns)
     AL(pressure, ns) AL(soundspeed, ns) AL(scale_height, ns) AL(viscosity, ns) AL(temperature, ns)
     AL(potential, ns)
     AL(sigma0, ns) AL(vrad0, nv) AL(vazi0, ns) AL(energy0, ns)
@@ -274,6 +293,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     AL(rmpA, ns) AL(rmmA, ns) AL(lpA, ns) AL(lmA, ns) AL(sigA, ns) AL(eA, ns)
     AL(rmpB, ns) AL(rmmB, ns) AL(lpB, ns) AL(lmB, ns) AL(sigB, ns) AL(eB, ns)
     AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1)
+    AL(cfl_part, (size_t)(nr + 256) * (size_t)((nphi + 255) / 256 + 1))
 #undef AL
     if (!rc && hipHostMalloc((void **)&c->h_clk, sizeof(DevClock)) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -370,6 +390,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         fcpt_destroy(c);
         return FCPT_EHIP;
     }
+    if (const char *e = getenv("FCPT_FUSED_SOURCE"))
+        c->fused_source = e[0] != '0';
     *out = c;
     return FCPT_OK;
 }

@@ -60,6 +60,7 @@ struct Dev {
     const double *cosphi, *sinphi; // cos/sin(dphi * j), j < nphi (SideEuler.cpp:60-63)
     // state
     double *sigma, *vrad, *vazi, *energy;
+    double *vrad_b, *vazi_b; // intermediate velocities of the fused source step
     // derived
     double *pressure, *soundspeed, *scale_height, *viscosity, *temperature, *potential;
     // reference (t = 0) copies
@@ -72,6 +73,7 @@ struct Dev {
     double *vmean;  // per ring <v_phi>
     double *vconst; // per ring constant residual velocity
     int *nshift;    // per ring integer shift
+    double *cfl_part; // per-block maxima of the CFL reduction
     DevClock *clk;
     // split
     int zero_no_ghost, one_no_ghost_vr, max_no_ghost, maxmo_no_ghost_vr, first_active, active_size;

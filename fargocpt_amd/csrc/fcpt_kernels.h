@@ -42,7 +42,10 @@ void launch_substep3(const Dev &P, int update_energy, hipStream_t st);
 void launch_boundary(const Dev &P, hipStream_t st);
 void launch_damping(const Dev &P, double *q, double *q0, const double *radius, const DampRange &r,
                     int is_density, hipStream_t st);
-void launch_transport(const Dev &P, hipStream_t st);
+void launch_transport(const Dev &P, const Dev &W, hipStream_t st);
+void launch_source_fused(const Dev &P, hipStream_t st);
+void launch_viscous_fused(const Dev &P, hipStream_t st);
+void launch_substep3_after_fused(const Dev &P, hipStream_t st);
 void launch_derived(const Dev &P, hipStream_t st);
 void launch_pressure(const Dev &P, hipStream_t st);
 void launch_temperature(const Dev &P, hipStream_t st);

@@ -6,11 +6,14 @@
 // the CPU path to rounding.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fcpt_kernels.h"
 
 namespace fcpt {
 
-#define IDX(i, j) ((size_t)(i) * (size_t)P.nphi + (size_t)(j))
+// 32-bit cell index: fcpt_create rejects grids with (nr+1)*nphi >= 2^31
+#define IDX(i, j) ((i) * P.nphi + (j))
 
 // One thread per cell; a 256-thread block is bx (phi) x by (rings), bx = the
 // smallest power of two >= nphi capped at 256, so narrow pseudo-1D grids
@@ -29,20 +32,38 @@ static inline Launch2D launch2d(int nrows, int nphi)
     l.grid = dim3((nphi + bx - 1) / bx, (nrows + by - 1) / by, 1);
     return l;
 }
-#define CELL(row0, nrows)                                        \
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;         \
-    const int i = (row0) + blockIdx.y * blockDim.y + threadIdx.y; \
-    if (j >= P.nphi || i >= (row0) + (nrows))                    \
-        return;
+// ROWU (template parameter of every 2-D kernel): the block is at least one wavefront wide in
+// phi, so all lanes of a wavefront share the ring index.  Promoting it to a scalar register
+// turns every per-ring geometry access (Rmed[i], InvSurf[i], ...) into a scalar-cache load
+// instead of a 64-lane vector load with full memory latency.
+#define CELL(row0, nrows)                                            \
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;             \
+    const int i_ = (row0) + blockIdx.y * blockDim.y + threadIdx.y;   \
+    if (j >= P.nphi || i_ >= (row0) + (nrows))                       \
+        return;                                                      \
+    const int i = ROWU ? __builtin_amdgcn_readfirstlane(i_) : i_;
 #define JNEXT (j == P.nphi - 1 ? 0 : j + 1)
 #define JPREV (j == 0 ? P.nphi - 1 : j - 1)
+
+// Reciprocal from v_rcp_f64 (~2^-26) refined by two Newton steps: ~1 ulp, less than half the
+// issue cost of the IEEE division sequence.  Used only where the result feeds a limited
+// slope or a specific quantity (errors of a few ulp there are far inside the 1e-10 parity bar).
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
 
 __device__ __forceinline__ double dmin(double a, double b) { return b < a ? b : a; } // std::min
 __device__ __forceinline__ double dmax(double a, double b) { return a < b ? b : a; } // std::max
 
 // ---------------------------------------------------------------------------
 // Pframeforce.cpp:21-94 CalculateNbodyPotential (+ Force.cpp:124-159 smoothing)
-__global__ void k_potential(const Dev P)
+template <bool ROWU> __global__ void k_potential(const Dev P)
 {
     CELL(0, P.nr);
     const double x = P.Rmed[i] * P.cosphi[j];
@@ -67,7 +88,7 @@ __global__ void k_potential(const Dev P)
 }
 
 // SourceEuler.cpp:325-372 momentum_update_radial
-__global__ void k_source_vr(const Dev P)
+template <bool ROWU> __global__ void k_source_vr(const Dev P)
 {
     CELL(P.one_no_ghost_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr);
     const double dt = P.clk->dt;
@@ -85,7 +106,7 @@ __global__ void k_source_vr(const Dev P)
 }
 
 // SourceEuler.cpp:375-428 momentum_update_azimuthal
-__global__ void k_source_va(const Dev P)
+template <bool ROWU> __global__ void k_source_va(const Dev P)
 {
     CELL(P.zero_no_ghost, P.max_no_ghost - P.zero_no_ghost);
     const double dt = P.clk->dt;
@@ -98,7 +119,7 @@ __global__ void k_source_va(const Dev P)
 }
 
 // SourceEuler.cpp:459-493 compression_heating
-__global__ void k_compression_heating(const Dev P)
+template <bool ROWU> __global__ void k_compression_heating(const Dev P)
 {
     CELL(0, P.nr - 1);
     const double dt = P.clk->dt;
@@ -111,7 +132,7 @@ __global__ void k_compression_heating(const Dev P)
 }
 
 // viscosity/artificial_viscosity.cpp:48-88 TW: Q_rr, Q_pp (+ dissipation)
-__global__ void k_tw_q(const Dev P)
+template <bool ROWU> __global__ void k_tw_q(const Dev P)
 {
     CELL(0, P.nr);
     const double dt = P.clk->dt;
@@ -137,7 +158,7 @@ __global__ void k_tw_q(const Dev P)
     }
 }
 // viscosity/artificial_viscosity.cpp:90-117 TW: v_phi
-__global__ void k_tw_va(const Dev P)
+template <bool ROWU> __global__ void k_tw_va(const Dev P)
 {
     CELL(1, P.nr - 2);
     const double dt = P.clk->dt;
@@ -148,7 +169,7 @@ __global__ void k_tw_va(const Dev P)
     P.vazi[IDX(i, j)] += dVp;
 }
 // viscosity/artificial_viscosity.cpp:119-139 TW: v_r
-__global__ void k_tw_vr(const Dev P)
+template <bool ROWU> __global__ void k_tw_vr(const Dev P)
 {
     CELL(P.one_no_ghost_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr);
     const double dt = P.clk->dt;
@@ -160,7 +181,7 @@ __global__ void k_tw_vr(const Dev P)
     P.vrad[IDX(i, j)] += dVr;
 }
 // viscosity/artificial_viscosity.cpp:165-189 SN: q_r, q_phi
-__global__ void k_sn_q(const Dev P)
+template <bool ROWU> __global__ void k_sn_q(const Dev P)
 {
     CELL(0, P.nr);
     const int jn = JNEXT;
@@ -172,7 +193,7 @@ __global__ void k_sn_q(const Dev P)
     P.qphi[IDX(i, j)] = dv_phi < 0.0 ? C2 * rho * (dv_phi * dv_phi) : 0.0;
 }
 // viscosity/artificial_viscosity.cpp:194-218 SN: energy dissipation
-__global__ void k_sn_e(const Dev P)
+template <bool ROWU> __global__ void k_sn_e(const Dev P)
 {
     CELL(P.zero_no_ghost, P.max_no_ghost - P.zero_no_ghost);
     const double dt = P.clk->dt;
@@ -184,7 +205,7 @@ __global__ void k_sn_e(const Dev P)
                           dt * P.qphi[IDX(i, j)] * dv_phi * invdxtheta;
 }
 // viscosity/artificial_viscosity.cpp:220-230 SN: v_r
-__global__ void k_sn_vr(const Dev P)
+template <bool ROWU> __global__ void k_sn_vr(const Dev P)
 {
     CELL(P.one_no_ghost_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr);
     const double dt = P.clk->dt;
@@ -192,7 +213,7 @@ __global__ void k_sn_vr(const Dev P)
                                                 (P.qr[IDX(i, j)] - P.qr[IDX(i - 1, j)]) * P.InvDiffRmed[i];
 }
 // viscosity/artificial_viscosity.cpp:232-248 SN: v_phi
-__global__ void k_sn_va(const Dev P)
+template <bool ROWU> __global__ void k_sn_va(const Dev P)
 {
     CELL(P.zero_no_ghost, P.max_no_ghost - P.zero_no_ghost);
     const double dt = P.clk->dt;
@@ -213,7 +234,7 @@ __device__ __forceinline__ double clamp_energy(const Dev &P, double e, double rh
         e = e_max;
     return e;
 }
-__global__ void k_temperature_range(const Dev P)
+template <bool ROWU> __global__ void k_temperature_range(const Dev P)
 {
     CELL(0, P.nr);
     P.energy[IDX(i, j)] = clamp_energy(P, P.energy[IDX(i, j)], P.sigma[IDX(i, j)]);
@@ -221,7 +242,7 @@ __global__ void k_temperature_range(const Dev P)
 
 // SourceEuler.cpp:1054-1092 compute_sound_speed_normal + :1218-1251 compute_scale_height_old
 // (adiabatic branch; the isothermal values are set once by k_iso_cs_h)
-__global__ void k_adi_cs_h(const Dev P)
+template <bool ROWU> __global__ void k_adi_cs_h(const Dev P)
 {
     CELL(0, P.nr);
     const double cs = sqrt(P.gamma * (P.gamma - 1.0) * P.energy[IDX(i, j)] / P.sigma[IDX(i, j)]);
@@ -230,7 +251,7 @@ __global__ void k_adi_cs_h(const Dev P)
     const double inv_omega_kepler = 1.0 / sqrt(P.G * P.Mc / (r * r * r));
     P.scale_height[IDX(i, j)] = cs / (sqrt(P.gamma)) * inv_omega_kepler;
 }
-__global__ void k_iso_cs_h(const Dev P, const double *cs_ring)
+template <bool ROWU> __global__ void k_iso_cs_h(const Dev P, const double *cs_ring)
 {
     CELL(0, P.nr);
     const double cs = cs_ring[i]; // h0 r^beta sqrt(GM/r), evaluated on the host (libm pow)
@@ -240,7 +261,7 @@ __global__ void k_iso_cs_h(const Dev P, const double *cs_ring)
     P.scale_height[IDX(i, j)] = cs * inv_omega_kepler;
 }
 // viscosity/viscosity.cpp:98-137 update_viscosity
-__global__ void k_viscosity(const Dev P)
+template <bool ROWU> __global__ void k_viscosity(const Dev P)
 {
     CELL(0, P.nr);
     if (P.alpha_viscosity)
@@ -249,7 +270,7 @@ __global__ void k_viscosity(const Dev P)
         P.viscosity[IDX(i, j)] = P.nu_const;
 }
 // SourceEuler.cpp:1442-1473 compute_pressure
-__global__ void k_pressure(const Dev P)
+template <bool ROWU> __global__ void k_pressure(const Dev P)
 {
     CELL(0, P.nr);
     if (P.adiabatic) {
@@ -260,7 +281,7 @@ __global__ void k_pressure(const Dev P)
     }
 }
 // SourceEuler.cpp:1475-1505 compute_temperature
-__global__ void k_temperature(const Dev P)
+template <bool ROWU> __global__ void k_temperature(const Dev P)
 {
     CELL(0, P.nr);
     if (P.adiabatic) {
@@ -272,7 +293,7 @@ __global__ void k_temperature(const Dev P)
 }
 
 // viscosity/viscosity.cpp:149-209: div v, tau_rr, tau_phiphi
-__global__ void k_stress_diag(const Dev P)
+template <bool ROWU> __global__ void k_stress_diag(const Dev P)
 {
     CELL(0, P.nr);
     const int jn = JNEXT;
@@ -288,7 +309,7 @@ __global__ void k_stress_diag(const Dev P)
     P.tpp[IDX(i, j)] = 2.0 * nu * sigma * (dpp - 1.0 / 3.0 * divv);
 }
 // viscosity/viscosity.cpp:211-254: tau_rphi on rows 1..Nr-1 (rows 0 and Nr stay 0)
-__global__ void k_stress_rphi(const Dev P)
+template <bool ROWU> __global__ void k_stress_rphi(const Dev P)
 {
     CELL(1, P.nr - 1);
     const int jp = JPREV;
@@ -303,7 +324,7 @@ __global__ void k_stress_rphi(const Dev P)
     P.trp[IDX(i, j)] = nu * sigma * drp;
 }
 // viscosity/viscosity.cpp:368-394: v_phi update
-__global__ void k_visc_va(const Dev P)
+template <bool ROWU> __global__ void k_visc_va(const Dev P)
 {
     CELL(1, P.nr - 2);
     const double dt = P.clk->dt;
@@ -317,7 +338,7 @@ __global__ void k_visc_va(const Dev P)
     P.vazi[IDX(i, j)] += dVp;
 }
 // viscosity/viscosity.cpp:396-421: v_r update
-__global__ void k_visc_vr(const Dev P)
+template <bool ROWU> __global__ void k_visc_vr(const Dev P)
 {
     CELL(P.one_no_ghost_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr);
     const double dt = P.clk->dt;
@@ -332,7 +353,7 @@ __global__ void k_visc_vr(const Dev P)
 
 // SourceEuler.cpp:614-630 calculate_qplus + :496-536 viscous_heating and
 // :931-950 calculate_qminus (all cooling terms are out of scope: Q- = 0)
-__global__ void k_qplus_qminus(const Dev P)
+template <bool ROWU> __global__ void k_qplus_qminus(const Dev P)
 {
     CELL(0, P.nr);
     double qplus = 0.0;
@@ -361,7 +382,7 @@ __device__ __forceinline__ double substep3_alpha(const Dev &P, double H, double 
 }
 // SourceEuler.cpp:1000-1048: energy update of SubStep3 (update_energy != 0) or only the
 // alpha rescaling of compute_heating_cooling_for_CFL (:1520-1545)
-__global__ void k_substep3(const Dev P, int update_energy)
+template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
 {
     CELL(1, P.nr - 2);
     const double dt = P.clk->dt;
@@ -383,6 +404,246 @@ __global__ void k_substep3(const Dev P, int update_energy)
     }
     P.qplus[IDX(i, j)] = Qplus;
     P.qminus[IDX(i, j)] = Qminus;
+}
+
+
+// ===========================================================================
+// Fused source step (default path).  The reference's source / artificial-viscosity /
+// viscous-stress substeps are 13 loop nests that stream ~45 grids; here they are three
+// out-of-place kernels that stream 17: intermediate tensors (Q_rr, Q_pp, div v, tau_*) are
+// re-evaluated from the velocities in registers instead of being stored.
+//   k_src_fused : (v_r, v_phi)   -> (v_r_b, v_phi_b)   S1 + S2
+//   k_av_fused  : (v_r_b,v_phi_b)-> (v_r, v_phi) [,e]  S3 + artificial viscosity (+ T range)
+//   k_visc_fused: (v_r, v_phi)   -> (v_r_b, v_phi_b)   stress tensor + viscous update [+ Q+]
+// Row ranges are those of the individual loops; rows outside a range are copied through.
+
+// SourceEuler.cpp:325-428 momentum_update_radial + momentum_update_azimuthal
+template <bool ROWU> __global__ void k_src_fused(const Dev P)
+{
+    CELL(0, P.nr + 1);
+    const double dt = P.clk->dt;
+    const int jn = JNEXT, jp = JPREV;
+    double vr = P.vrad[IDX(i, j)];
+    if (i >= P.one_no_ghost_vr && i < P.maxmo_no_ghost_vr) {
+        double gradp = 2.0 / (P.sigma[IDX(i, j)] + P.sigma[IDX(i - 1, j)]);
+        gradp *= (P.pressure[IDX(i, j)] - P.pressure[IDX(i - 1, j)]);
+        gradp *= P.InvDiffRmed[i];
+        const double gradphi = (P.potential[IDX(i, j)] - P.potential[IDX(i - 1, j)]) * P.InvDiffRmed[i];
+        const double vsum =
+            P.vazi[IDX(i, j)] + P.vazi[IDX(i, jn)] + P.vazi[IDX(i - 1, j)] + P.vazi[IDX(i - 1, jn)];
+        const double vt = 0.25 * vsum + P.Rinf[i] * P.omega_frame;
+        const double vt2 = vt * vt;
+        vr += dt * (-gradp - gradphi + vt2 * P.InvRinf[i]);
+    }
+    P.vrad_b[IDX(i, j)] = vr;
+    if (i < P.nr) {
+        double va = P.vazi[IDX(i, j)];
+        if (i >= P.zero_no_ghost && i < P.max_no_ghost) {
+            const double invdxtheta = 2.0 / (P.dphi * (P.Rsup[i] + P.Rinf[i]));
+            const double gradp = 2.0 / (P.sigma[IDX(i, j)] + P.sigma[IDX(i, jp)]) *
+                                 (P.pressure[IDX(i, j)] - P.pressure[IDX(i, jp)]) * invdxtheta;
+            const double gradphi = (P.potential[IDX(i, j)] - P.potential[IDX(i, jp)]) * invdxtheta;
+            va = va + dt * (-gradp - gradphi);
+        }
+        P.vazi_b[IDX(i, j)] = va;
+    }
+}
+
+struct TwQ {
+    double qrr, qpp, eps_rr, eps_pp, div_V, l_sq;
+};
+// artificial_viscosity.cpp:48-77 at cell (i, j), velocities from the *_b buffers
+__device__ __forceinline__ TwQ tw_q_at(const Dev &P, int i, int j)
+{
+    const int jn = JNEXT;
+    const double vr0 = P.vrad_b[IDX(i, j)], vr1 = P.vrad_b[IDX(i + 1, j)];
+    TwQ q;
+    q.eps_rr = (vr1 - vr0) * P.InvDiffRsup[i];
+    q.eps_pp = P.InvRmed[i] * ((P.vazi_b[IDX(i, jn)] - P.vazi_b[IDX(i, j)]) * P.invdphi + 0.5 * (vr1 + vr0));
+    q.div_V = dmin(q.eps_rr + q.eps_pp, 0.0);
+    const double Dr = P.Rinf[i + 1] - P.Rinf[i];
+    const double rDphi = P.Rmed[i] * P.dphi;
+    const double dx = P.nphi <= 16 ? dmin(Dr, rDphi) : dmax(Dr, rDphi);
+    q.l_sq = (P.art_visc_factor * P.art_visc_factor) * (dx * dx);
+    const double rho = P.sigma[IDX(i, j)];
+    q.qrr = q.l_sq * rho * -q.div_V * (q.eps_rr - 1.0 / 3.0 * q.div_V);
+    q.qpp = q.l_sq * rho * -q.div_V * (q.eps_pp - 1.0 / 3.0 * q.div_V);
+    return q;
+}
+// artificial_viscosity.cpp:165-189 at cell (i, j)
+__device__ __forceinline__ void sn_q_at(const Dev &P, int i, int j, double &qr, double &qphi)
+{
+    const int jn = JNEXT;
+    const double C2 = P.art_visc_factor * P.art_visc_factor;
+    const double rho = P.sigma[IDX(i, j)];
+    const double dv_r = P.vrad_b[IDX(i + 1, j)] - P.vrad_b[IDX(i, j)];
+    qr = dv_r < 0.0 ? C2 * rho * (dv_r * dv_r) : 0.0;
+    const double dv_phi = P.vazi_b[IDX(i, jn)] - P.vazi_b[IDX(i, j)];
+    qphi = dv_phi < 0.0 ? C2 * rho * (dv_phi * dv_phi) : 0.0;
+}
+
+// compression_heating (SourceEuler.cpp:459-493) + update_with_artificial_viscosity
+// (artificial_viscosity.cpp:11-250) incl. the temperature floor/ceiling
+template <bool ROWU> __global__ void k_av_fused(const Dev P)
+{
+    CELL(0, P.nr + 1);
+    const double dt = P.clk->dt;
+    const int jn = JNEXT, jp = JPREV;
+    const int nr = P.nr;
+    double vr = P.vrad_b[IDX(i, j)];
+    if (i == nr) {
+        P.vrad[IDX(i, j)] = vr;
+        return;
+    }
+    double va = P.vazi_b[IDX(i, j)];
+    double e = P.adiabatic ? P.energy[IDX(i, j)] : 0.0;
+    if (P.adiabatic && i < nr - 1) { // compression heating, rows [0, Nr-1)
+        const double DIV_V =
+            (P.vrad_b[IDX(i + 1, j)] * P.Rinf[i + 1] - vr * P.Rinf[i]) * P.InvDiffRsupRb[i] +
+            (P.vazi_b[IDX(i, jn)] - va) * P.invdphi * P.InvRmed[i];
+        e = e * exp(-(P.gamma - 1.0) * dt * DIV_V);
+    }
+    const bool upd_vr = i >= P.one_no_ghost_vr && i < P.maxmo_no_ghost_vr;
+    if (P.art_visc == FCPT_ARTVISC_TW) {
+        const TwQ q = tw_q_at(P, i, j);
+        if (P.adiabatic && P.art_visc_dissipation && i > P.zero_no_ghost && i < P.max_no_ghost) {
+            const double Qplus = -q.l_sq * q.div_V * P.sigma[IDX(i, j)] * 1.0 / 3.0 *
+                                 (q.eps_rr * q.eps_rr + q.eps_pp * q.eps_pp +
+                                  (q.eps_rr - q.eps_pp) * (q.eps_rr - q.eps_pp));
+            e += Qplus * dt;
+        }
+        if (i >= 1 && i < nr - 1) {
+            const TwQ qm = tw_q_at(P, i, jp);
+            const double sigma_phi_avg = 0.5 * (P.sigma[IDX(i, j)] + P.sigma[IDX(i, jp)]);
+            va += 2.0 * dt / ((P.Rsup[i] + P.Rinf[i]) * sigma_phi_avg) * (q.qpp - qm.qpp) * P.invdphi;
+        }
+        if (upd_vr) {
+            const TwQ qi = tw_q_at(P, i - 1, j);
+            const double sigma_r_avg = 0.5 * (P.sigma[IDX(i, j)] + P.sigma[IDX(i - 1, j)]);
+            const double rm = P.Rmed[i], rmm = P.Rmed[i - 1];
+            vr += P.radial_viscosity_factor * dt / sigma_r_avg * 2.0 / (rm * rm - rmm * rmm) *
+                  ((q.qrr * rm - qi.qrr * rmm) - 0.5 * (q.qpp + qi.qpp) * (rm - rmm));
+        }
+    } else if (P.art_visc == FCPT_ARTVISC_SN) {
+        double qr, qphi;
+        sn_q_at(P, i, j, qr, qphi);
+        const double invdxtheta = 1.0 / (P.dphi * P.Rmed[i]);
+        const bool row_va = i >= P.zero_no_ghost && i < P.max_no_ghost;
+        if (P.adiabatic && P.art_visc_dissipation && row_va) {
+            const double dv_r = P.vrad_b[IDX(i + 1, j)] - vr;
+            const double dv_phi = P.vazi_b[IDX(i, jn)] - va;
+            e = e - dt * qr * dv_r * P.InvDiffRsup[i] - dt * qphi * dv_phi * invdxtheta;
+        }
+        if (upd_vr) {
+            double qr_m, qphi_m;
+            sn_q_at(P, i - 1, j, qr_m, qphi_m);
+            vr = vr - dt * 2.0 / (P.sigma[IDX(i, j)] + P.sigma[IDX(i - 1, j)]) * (qr - qr_m) * P.InvDiffRmed[i];
+        }
+        if (row_va) {
+            double qr_p, qphi_p;
+            sn_q_at(P, i, jp, qr_p, qphi_p);
+            va = va - dt * 2.0 / (P.sigma[IDX(i, j)] + P.sigma[IDX(i, jp)]) * (qphi - qphi_p) * invdxtheta;
+        }
+    }
+    P.vrad[IDX(i, j)] = vr;
+    P.vazi[IDX(i, j)] = va;
+    if (P.adiabatic) {
+        if (P.art_visc_dissipation)
+            e = clamp_energy(P, e, P.sigma[IDX(i, j)]);
+        P.energy[IDX(i, j)] = e;
+    }
+}
+
+struct TauDiag {
+    double divv, trr, tpp;
+};
+// viscosity.cpp:149-209 at cell (i, j), 0 <= i < Nr
+__device__ __forceinline__ TauDiag tau_diag_at(const Dev &P, int i, int j)
+{
+    const int jn = JNEXT;
+    const double vr0 = P.vrad[IDX(i, j)], vr1 = P.vrad[IDX(i + 1, j)];
+    const double dva = P.vazi[IDX(i, jn)] - P.vazi[IDX(i, j)];
+    TauDiag t;
+    t.divv = (vr1 * P.Rinf[i + 1] - vr0 * P.Rinf[i]) * P.InvDiffRsupRb[i] + dva * P.invdphi * P.InvRmed[i];
+    const double nu = P.viscosity[IDX(i, j)], sigma = P.sigma[IDX(i, j)];
+    const double drr = (vr1 - vr0) * P.InvDiffRsup[i];
+    t.trr = 2.0 * nu * sigma * (drr - 1.0 / 3.0 * t.divv);
+    const double dpp = dva * P.invdphi * P.InvRmed[i] + 0.5 * (vr1 + vr0) * P.InvRmed[i];
+    t.tpp = 2.0 * nu * sigma * (dpp - 1.0 / 3.0 * t.divv);
+    return t;
+}
+// viscosity.cpp:211-254 at corner (i, j); rows 0 and Nr are never written (stay 0)
+__device__ __forceinline__ double tau_rp_at(const Dev &P, int i, int j)
+{
+    if (i < 1 || i > P.nr - 1)
+        return 0.0;
+    const int jp = JPREV;
+    const double dvazirdr =
+        (P.vazi[IDX(i, j)] * P.InvRmed[i] - P.vazi[IDX(i - 1, j)] * P.InvRmed[i - 1]) * P.InvDiffRmed[i];
+    const double dvrdphi = (P.vrad[IDX(i, j)] - P.vrad[IDX(i, jp)]) * P.invdphi;
+    const double drp = P.Rinf[i] * dvazirdr + dvrdphi * P.InvRinf[i];
+    const double nu = 0.25 * (P.viscosity[IDX(i, j)] + P.viscosity[IDX(i - 1, j)] + P.viscosity[IDX(i, jp)] +
+                              P.viscosity[IDX(i - 1, jp)]);
+    const double sigma =
+        0.25 * (P.sigma[IDX(i, j)] + P.sigma[IDX(i - 1, j)] + P.sigma[IDX(i, jp)] + P.sigma[IDX(i - 1, jp)]);
+    return nu * sigma * drp;
+}
+// compute_viscous_stress_tensor + update_velocities_with_viscosity (viscosity.cpp:139-426)
+// and, for the energy equation, viscous_heating (SourceEuler.cpp:496-536) into QPLUS
+template <bool ROWU> __global__ void k_visc_fused(const Dev P)
+{
+    CELL(0, P.nr + 1);
+    const double dt = P.clk->dt;
+    const int jn = JNEXT, jp = JPREV;
+    const int nr = P.nr;
+    double vr = P.vrad[IDX(i, j)];
+    if (i == nr) {
+        P.vrad_b[IDX(i, j)] = vr;
+        return;
+    }
+    double va = P.vazi[IDX(i, j)];
+    const TauDiag t = tau_diag_at(P, i, j);
+    const double trp = tau_rp_at(P, i, j);
+    double trp_ip = 0.0;
+    const bool row_va = i >= 1 && i < nr - 1;
+    if (row_va) {
+        trp_ip = tau_rp_at(P, i + 1, j);
+        const TauDiag tjp = tau_diag_at(P, i, jp);
+        const double sigma_avg = 0.5 * (P.sigma[IDX(i, j)] + P.sigma[IDX(i, jp)]);
+        const double ra1 = P.Rinf[i + 1], ra0 = P.Rinf[i];
+        va += dt * P.InvRmed[i] / (sigma_avg) *
+              ((2.0 / (ra1 * ra1 - ra0 * ra0)) * (ra1 * ra1 * trp_ip - ra0 * ra0 * trp) +
+               (t.tpp - tjp.tpp) * P.invdphi);
+    }
+    double trp_jn = 0.0;
+    if (i >= P.one_no_ghost_vr && i < P.maxmo_no_ghost_vr) {
+        trp_jn = tau_rp_at(P, i, jn);
+        const TauDiag tim = tau_diag_at(P, i - 1, j);
+        const double sigma_avg = 0.5 * (P.sigma[IDX(i, j)] + P.sigma[IDX(i - 1, j)]);
+        vr += dt / (sigma_avg)*P.radial_viscosity_factor * 2.0 / (P.Rmed[i] + P.Rmed[i - 1]) *
+              ((P.Rmed[i] * t.trr - P.Rmed[i - 1] * tim.trr) * P.InvDiffRmed[i] + (trp_jn - trp) * P.invdphi -
+               0.5 * (t.tpp + tim.tpp));
+    }
+    P.vrad_b[IDX(i, j)] = vr;
+    P.vazi_b[IDX(i, j)] = va;
+    if (P.adiabatic) {
+        double qplus = 0.0;
+        if (P.heating_viscous && row_va) {
+            const double nu = P.viscosity[IDX(i, j)];
+            if (nu != 0.0) {
+                if (!(i >= P.one_no_ghost_vr && i < P.maxmo_no_ghost_vr))
+                    trp_jn = tau_rp_at(P, i, jn);
+                const double tau_r_phi = 0.25 * (trp + trp_ip + trp_jn + tau_rp_at(P, i + 1, jn));
+                const double sigma = P.sigma[IDX(i, j)];
+                double q = 1.0 / (2.0 * nu * sigma) * (t.trr * t.trr + 2 * (tau_r_phi * tau_r_phi) + t.tpp * t.tpp);
+                q += (2.0 / 9.0) * nu * sigma * (t.divv * t.divv);
+                q *= P.heating_viscous_factor;
+                qplus += q;
+            }
+        }
+        P.qplus[IDX(i, j)] = qplus;
+        P.qminus[IDX(i, j)] = 0.0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -542,28 +803,48 @@ __device__ __forceinline__ double limiter(int type, double a, double b)
             return fabs(c) < fabs(d) ? c : d;
         return 0.0;
     }
-    if (a * b > 0.0)
-        return 2.0 * a * b / (a + b);
-    return 0.0;
+    const double ab = a * b;
+    return ab > 0.0 ? 2.0 * ab * fast_rcp(a + b) : 0.0;
 }
 
 // Upwind "star" state at radial interface k (between rings k-1 and k),
 // compute_star_radial (TransportEuler.cpp:349-406).  wm2..wp1 = Q at rings k-2..k+1.
-__device__ __forceinline__ double star_radial(const Dev &P, int k, double v, double dt, double wm2,
-                                              double wm1, double w0, double wp1)
+// Per-interface geometry of compute_star_radial, loaded once with the (wavefront-uniform)
+// interface index so it lives in scalar registers; the upwind choice then only selects
+// between preloaded values instead of issuing lane-divergent loads.
+struct StarGeo {
+    double idr_m, idr_0, idr_p; // InvDiffRmed[k-1], [k], [k+1]
+    double dr_lo, dr_hi;        // Rmed[k]-Rmed[k-1], Rmed[k+1]-Rmed[k]
+    bool lim_lo, lim_hi;        // slope of ring k-1 / ring k is limited (not a closed boundary ring)
+    bool open;                  // interface carries a flux (0 < k < Nr)
+};
+__device__ __forceinline__ StarGeo star_geo(const Dev &P, int k)
 {
-    if (k <= 0 || k >= P.nr)
+    StarGeo g;
+    g.open = k > 0 && k < P.nr;
+    const int kk = g.open ? k : 1;
+    g.idr_m = P.InvDiffRmed[kk - 1];
+    g.idr_0 = P.InvDiffRmed[kk];
+    g.idr_p = P.InvDiffRmed[kk + 1];
+    g.dr_lo = P.Rmed[kk] - P.Rmed[kk - 1];
+    g.dr_hi = P.Rmed[kk + 1] - P.Rmed[kk];
+    g.lim_lo = (kk - 1 != 0) && (kk - 1 != P.nr - 1);
+    g.lim_hi = (kk != 0) && (kk != P.nr - 1);
+    return g;
+}
+__device__ __forceinline__ double star_radial(const Dev &P, const StarGeo &g, double v, double dt,
+                                              double wm2, double wm1, double w0, double wp1)
+{
+    if (!g.open)
         return 0.0; // row 0 is zeroed on every call, row Nr is never written
-    if (v > 0.0) {
-        double dq = 0.0;
-        if (k - 1 != 0 && k - 1 != P.nr - 1)
-            dq = limiter(P.limiter, (w0 - wm1) * P.InvDiffRmed[k], (wm1 - wm2) * P.InvDiffRmed[k - 1]);
-        return wm1 + (P.Rmed[k] - P.Rmed[k - 1] - v * dt) * 0.5 * dq;
-    }
-    double dq = 0.0;
-    if (k != 0 && k != P.nr - 1)
-        dq = limiter(P.limiter, (wp1 - w0) * P.InvDiffRmed[k + 1], (w0 - wm1) * P.InvDiffRmed[k]);
-    return w0 - (P.Rmed[k + 1] - P.Rmed[k] + v * dt) * 0.5 * dq;
+    // upwind cell c = k-1 (v > 0) or k; one limiter evaluation on the selected stencil
+    const bool up = v > 0.0;
+    const double x0 = up ? wm2 : wm1, x1 = up ? wm1 : w0, x2 = up ? w0 : wp1;
+    const double ihi = up ? g.idr_0 : g.idr_p, ilo = up ? g.idr_m : g.idr_0;
+    const bool lim = up ? g.lim_lo : g.lim_hi;
+    const double dq = lim ? limiter(P.limiter, (x2 - x1) * ihi, (x1 - x0) * ilo) : 0.0;
+    const double dist = up ? (g.dr_lo - v * dt) : -(g.dr_hi + v * dt);
+    return x1 + dist * 0.5 * dq;
 }
 
 // compute_momenta_from_velocities (:471-493) + OneWindRad (:138-167) with all
@@ -571,72 +852,102 @@ __device__ __forceinline__ double star_radial(const Dev &P, int k, double v, dou
 // writes the transported momenta / density / energy to set B, so the in-place
 // ordering constraint of the reference ("Sigma MUST be last") is met by
 // construction: every quantity sees the pre-transport density.
-__global__ void k_transport_radial(const Dev P)
+//
+// One thread owns a phi column and marches RADIAL_ROWS rings outward keeping the
+// 4-ring stencil of every specific quantity in registers, so each interface flux
+// is evaluated once and each ring is loaded once per chunk (+4 halo rings).
+// The specific momenta Work = (Sigma v)/Sigma are formed as v directly (equal to
+// the reference's quotient to within 1 ulp).
+#define RADIAL_ROWS 16
+
+struct RadialRow { // specific quantities of one ring at this column (er: the energy itself)
+    double s, rmp, rmm, lp, lm, e, er;
+};
+__device__ __forceinline__ RadialRow radial_load(const Dev &P, int k, int j, int jn, double vr_k,
+                                                 double vr_k1)
 {
-    CELL(0, P.nr);
+    RadialRow w;
+    if (k >= 0 && k < P.nr) {
+        const double r = P.Rmed[k];
+        w.s = P.sigma[IDX(k, j)];
+        w.rmp = vr_k1;
+        w.rmm = vr_k;
+        w.lp = (P.vazi[IDX(k, jn)] + r * P.omega_frame) * r;
+        w.lm = (P.vazi[IDX(k, j)] + r * P.omega_frame) * r;
+        w.er = P.adiabatic ? P.energy[IDX(k, j)] : 0.0;
+        w.e = P.adiabatic ? w.er / w.s : 0.0;
+    } else {
+        w.s = w.rmp = w.rmm = w.lp = w.lm = w.e = w.er = 0.0;
+    }
+    return w;
+}
+struct RadialFlux {
+    double s, rmp, rmm, lp, lm, e;
+};
+// fluxes through interface k given rings k-2..k+1 (a,b,c,d) and v_r(k)
+__device__ __forceinline__ RadialFlux radial_flux(const Dev &P, int k, double v, double dt,
+                                                  const RadialRow &a, const RadialRow &b,
+                                                  const RadialRow &c, const RadialRow &d)
+{
+    RadialFlux f;
+    const StarGeo geo = star_geo(P, k);
+    if (!geo.open) { // closed: QRStar/DensityStar row 0 zeroed, row Nr never written
+        f.s = f.rmp = f.rmm = f.lp = f.lm = f.e = 0.0;
+        return f;
+    }
+    const double rho = star_radial(P, geo, v, dt, a.s, b.s, c.s, d.s);
+    const double g = dt * P.dphi * P.Rinf[k];
+    f.s = g * 1.0 * rho * v;
+    f.rmp = g * star_radial(P, geo, v, dt, a.rmp, b.rmp, c.rmp, d.rmp) * rho * v;
+    f.rmm = g * star_radial(P, geo, v, dt, a.rmm, b.rmm, c.rmm, d.rmm) * rho * v;
+    f.lp = g * star_radial(P, geo, v, dt, a.lp, b.lp, c.lp, d.lp) * rho * v;
+    f.lm = g * star_radial(P, geo, v, dt, a.lm, b.lm, c.lm, d.lm) * rho * v;
+    f.e = P.adiabatic ? g * star_radial(P, geo, v, dt, a.e, b.e, c.e, d.e) * rho * v : 0.0;
+    return f;
+}
+template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(const Dev P)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r0_ = (blockIdx.y * blockDim.y + threadIdx.y) * RADIAL_ROWS;
+    if (j >= P.nphi || r0_ >= P.nr)
+        return;
+    const int r0 = ROWU ? __builtin_amdgcn_readfirstlane(r0_) : r0_;
     const double dt = P.clk->dt;
     const int jn = JNEXT;
     const int nr = P.nr;
-    // rings i-2 .. i+2 of this column
-    double S[5], VR[6], W_rmp[5], W_rmm[5], W_lp[5], W_lm[5], W_e[5];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        const int k = i - 2 + a;
-        VR[a] = (k >= 0 && k <= nr) ? P.vrad[IDX(k, j)] : 0.0;
+    const int r1 = r0 + RADIAL_ROWS < nr ? r0 + RADIAL_ROWS : nr;
+    auto vr_at = [&](int k) { return (k >= 0 && k <= nr) ? P.vrad[IDX(k, j)] : 0.0; };
+    // rings r0-2 .. r0+2 (the last one is the software-prefetched ring of the next iteration:
+    // the marching loop is latency-bound unless each ring's loads are issued one iteration
+    // before their first use)
+    double v0 = vr_at(r0 - 2), v1 = vr_at(r0 - 1), v2 = vr_at(r0), v3 = vr_at(r0 + 1), v4 = vr_at(r0 + 2),
+           v5 = vr_at(r0 + 3);
+    RadialRow a = radial_load(P, r0 - 2, j, jn, v0, v1);
+    RadialRow b = radial_load(P, r0 - 1, j, jn, v1, v2);
+    RadialRow c = radial_load(P, r0, j, jn, v2, v3);
+    RadialRow d = radial_load(P, r0 + 1, j, jn, v3, v4);
+    RadialRow e = radial_load(P, r0 + 2, j, jn, v4, v5);
+    RadialFlux fin = radial_flux(P, r0, v2, dt, a, b, c, d);
+    for (int i = r0; i < r1; ++i) {
+        // prefetch ring i+3 (used by the next iteration)
+        const double v6 = vr_at(i + 4);
+        const RadialRow f = radial_load(P, i + 3, j, jn, v5, v6);
+        // rings i-1..i+2 around interface i+1
+        const RadialFlux fout = radial_flux(P, i + 1, v3, dt, b, c, d, e);
+        const double invsurf = P.InvSurf[i];
+        const double s0 = c.s;
+        // momenta of T1 for ring i (TransportEuler.cpp:484-490); c.lp/c.lm = (v_phi + r Omega) r
+        P.rmpB[IDX(i, j)] = s0 * v3 + (fin.rmp - fout.rmp) * invsurf;
+        P.rmmB[IDX(i, j)] = s0 * v2 + (fin.rmm - fout.rmm) * invsurf;
+        P.lpB[IDX(i, j)] = s0 * c.lp + (fin.lp - fout.lp) * invsurf;
+        P.lmB[IDX(i, j)] = s0 * c.lm + (fin.lm - fout.lm) * invsurf;
+        if (P.adiabatic)
+            P.eB[IDX(i, j)] = c.er + (fin.e - fout.e) * invsurf;
+        P.sigB[IDX(i, j)] = s0 + (fin.s - fout.s) * invsurf;
+        a = b; b = c; c = d; d = e; e = f;
+        v2 = v3; v3 = v4; v4 = v5; v5 = v6;
+        fin = fout;
     }
-#pragma unroll
-    for (int a = 0; a < 5; ++a) {
-        const int k = i - 2 + a;
-        if (k >= 0 && k < nr) {
-            const double s = P.sigma[IDX(k, j)];
-            const double r = P.Rmed[k];
-            const double va = P.vazi[IDX(k, j)], van = P.vazi[IDX(k, jn)];
-            S[a] = s;
-            // Work = Q / DENSITY_INT with Q the momentum of T1
-            W_rmp[a] = (s * VR[a + 1]) / s;
-            W_rmm[a] = (s * VR[a]) / s;
-            W_lp[a] = (s * (van + r * P.omega_frame) * r) / s;
-            W_lm[a] = (s * (va + r * P.omega_frame) * r) / s;
-            W_e[a] = P.adiabatic ? P.energy[IDX(k, j)] / s : 0.0;
-        } else {
-            S[a] = W_rmp[a] = W_rmm[a] = W_lp[a] = W_lm[a] = W_e[a] = 0.0;
-        }
-    }
-    // interfaces i (inf) and i+1 (sup)
-    const double v_inf = VR[2], v_sup = VR[3];
-    const double rho_inf = star_radial(P, i, v_inf, dt, S[0], S[1], S[2], S[3]);
-    const double rho_sup = star_radial(P, i + 1, v_sup, dt, S[1], S[2], S[3], S[4]);
-    const double f_inf = dt * P.dphi * P.Rinf[i];
-    const double f_sup = dt * P.dphi * P.Rsup[i];
-    const double invsurf = P.InvSurf[i];
-    const double s0 = S[2];
-#define RADIAL_UPDATE(W, Q0, OUT)                                                      \
-    {                                                                                  \
-        const double q_inf = star_radial(P, i, v_inf, dt, W[0], W[1], W[2], W[3]);     \
-        const double q_sup = star_radial(P, i + 1, v_sup, dt, W[1], W[2], W[3], W[4]); \
-        const double varq_inf = f_inf * q_inf * rho_inf * v_inf;                       \
-        const double varq_sup = f_sup * q_sup * rho_sup * v_sup;                       \
-        OUT[IDX(i, j)] = (Q0) + (varq_inf - varq_sup) * invsurf;                       \
-    }
-    RADIAL_UPDATE(W_rmp, s0 * VR[3], P.rmpB);
-    RADIAL_UPDATE(W_rmm, s0 * VR[2], P.rmmB);
-    {
-        const double r = P.Rmed[i];
-        const double va = P.vazi[IDX(i, j)], van = P.vazi[IDX(i, jn)];
-        RADIAL_UPDATE(W_lp, s0 * (van + r * P.omega_frame) * r, P.lpB);
-        RADIAL_UPDATE(W_lm, s0 * (va + r * P.omega_frame) * r, P.lmB);
-    }
-    if (P.adiabatic)
-        RADIAL_UPDATE(W_e, P.energy[IDX(i, j)], P.eB);
-    {
-        // density: Work = Sigma / DENSITY_INT = 1 exactly => star state 1 (0 on the closed rows)
-        const double q_inf = (i <= 0) ? 0.0 : 1.0;
-        const double q_sup = (i + 1 >= nr) ? 0.0 : 1.0;
-        const double varq_inf = f_inf * q_inf * rho_inf * v_inf;
-        const double varq_sup = f_sup * q_sup * rho_sup * v_sup;
-        P.sigB[IDX(i, j)] = s0 + (varq_inf - varq_sup) * invsurf;
-    }
-#undef RADIAL_UPDATE
 }
 
 // compute_average_azimuthal_velocity (:174-189) + ComputeConstantResidual (:207-236):
@@ -678,12 +989,11 @@ __device__ __forceinline__ double star_theta(const Dev &P, double v, double dt, 
                                              double wp1)
 {
     const double ksi = v * dt;
-    if (ksi > 0.0) {
-        const double dq = 0.5 * limiter(P.limiter, (w0 - wm1), (wm1 - wm2)) * invdxtheta;
-        return wm1 + (dxtheta - ksi) * dq;
-    }
-    const double dq = 0.5 * limiter(P.limiter, (wp1 - w0), (w0 - wm1)) * invdxtheta;
-    return w0 - (dxtheta + ksi) * dq;
+    const bool up = ksi > 0.0;
+    const double x0 = up ? wm2 : wm1, x1 = up ? wm1 : w0, x2 = up ? w0 : wp1;
+    const double dq = 0.5 * limiter(P.limiter, (x2 - x1), (x1 - x0)) * invdxtheta;
+    const double dist = up ? (dxtheta - ksi) : -(dxtheta + ksi);
+    return x1 + dist * dq;
 }
 
 struct ThetaSet {
@@ -697,7 +1007,7 @@ struct ThetaOut {
 // out of place.  PASS 1: residual velocity v_phi - <v_phi> (+ constant residual when the
 // FARGO split is off).  PASS 2: uniform residual, and the integer shift AdvectSHIFT
 // (:238-268) is applied by the store (cell j lands in j + Nshift).
-template <int PASS> __global__ void k_transport_theta(const Dev P, ThetaSet in, ThetaOut out)
+template <int PASS, bool ROWU> __global__ void k_transport_theta(const Dev P, ThetaSet in, ThetaOut out)
 {
     CELL(0, P.nr);
     const double dt = P.clk->dt;
@@ -744,16 +1054,18 @@ template <int PASS> __global__ void k_transport_theta(const Dev P, ThetaSet in, 
     const double invdxtheta = 1.0 / dxtheta;
     const double dxrad = (P.Rsup[i] - P.Rinf[i]) * dt;
     const double invsurf = P.InvSurf[i];
-    double S[5];
+    double S[5], rS[5]; // Work = Q * (1/Sigma): within 1 ulp of the reference's Q / Sigma
 #pragma unroll
-    for (int a = 0; a < 5; ++a)
+    for (int a = 0; a < 5; ++a) {
         S[a] = in.sig[IDX(i, jj[a])];
+        rS[a] = fast_rcp(S[a]);
+    }
     const double rho0 = star_theta(P, v0, dt, dxtheta, invdxtheta, S[0], S[1], S[2], S[3]);
     const double rho1 = star_theta(P, v1, dt, dxtheta, invdxtheta, S[1], S[2], S[3], S[4]);
 #define THETA_UPDATE(IN, OUT)                                                                    \
     {                                                                                            \
         double W[5];                                                                             \
-        _Pragma("unroll") for (int a = 0; a < 5; ++a) W[a] = IN[IDX(i, jj[a])] / S[a];           \
+        _Pragma("unroll") for (int a = 0; a < 5; ++a) W[a] = IN[IDX(i, jj[a])] * rS[a];         \
         const double q0 = star_theta(P, v0, dt, dxtheta, invdxtheta, W[0], W[1], W[2], W[3]);    \
         const double q1 = star_theta(P, v1, dt, dxtheta, invdxtheta, W[1], W[2], W[3], W[4]);    \
         double varq = dxrad * q0 * rho0 * v0;                                                    \
@@ -775,53 +1087,262 @@ template <int PASS> __global__ void k_transport_theta(const Dev P, ThetaSet in, 
 #undef THETA_UPDATE
 }
 
+
+// ---------------------------------------------------------------------------
+// OneWindTheta (:270-288) in ONE kernel: residual pass, uniform pass and the integer
+// shift.  A wavefront owns a segment of one ring; every lane keeps C contiguous cells of
+// all transported quantities in registers, neighbours' edge cells arrive by wavefront
+// shuffles (no LDS, no barriers), star states are evaluated once per interface.
+//   * "periodic" mode (Nphi <= 64 C, Nphi % C == 0): one wavefront holds the whole ring and
+//     the shuffles wrap around.
+//   * tiled mode: segments of 64 C cells advance by 64 C - 4; the residual pass is valid on
+//     the whole segment (its two-cell input halo is loaded), the uniform pass on all but two
+//     cells at each end, which the neighbouring segment owns.
+// Reads set B (+ v_phi, <v_phi>, Nshift), writes set A: 11 (13) doubles per cell.
+template <int C, bool ADI>
+__global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, ThetaSet in, ThetaOut out,
+                                                              int tiles, int periodic)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int i = wave / tiles;
+    if (i >= P.nr)
+        return;
+    const int tile = wave - i * tiles;
+    const int nphi = P.nphi;
+    const int nl = periodic == 1 ? nphi / C : 64;          // lanes that own cells
+    const int stride = periodic == 1 ? nphi : 64 * C - 4;
+    const int a = periodic == 1 ? 0 : tile * stride - 2;   // first cell of the segment, in [-2, nphi)
+    const bool act = lane < nl;
+    const int ln = act ? lane : 0;
+    int lsrc_l = ln - 1, lsrc_r = ln + 1;
+    if (periodic == 1) {
+        lsrc_l = lsrc_l < 0 ? nl - 1 : lsrc_l;
+        lsrc_r = lsrc_r >= nl ? 0 : lsrc_r;
+    } else {
+        lsrc_l = lsrc_l < 0 ? 0 : lsrc_l;
+        lsrc_r = lsrc_r > 63 ? 63 : lsrc_r;
+    }
+    const bool edge_l = periodic != 1 && lane == 0, edge_r = periodic != 1 && lane == 63;
+    const double dt = P.clk->dt;
+    const int row = i * nphi;
+    // all cell indices of a segment lie in [-4, 2 nphi): one conditional fold replaces '%'
+    auto wrap = [nphi](int j) { return j < 0 ? j + nphi : (j >= nphi ? j - nphi : j); };
+
+    int idx[C];
+    double S[C], Q[4][C], E[C], V[C + 1];
+    const double mean = P.vmean[i];
+    const double vconst = P.vconst[i];
+    const double vadd = P.fast_transport ? 0.0 : vconst; // ComputeConstantResidual, non-FARGO branch
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        idx[c] = wrap(periodic == 2 ? a + c * 64 + ln : a + ln * C + c);
+        const int g = row + idx[c];
+        S[c] = in.sig[g];
+        Q[0][c] = in.rmp[g];
+        Q[1][c] = in.rmm[g];
+        Q[2][c] = in.lp[g];
+        Q[3][c] = in.lm[g];
+        E[c] = ADI ? in.e[g] : 0.0;
+        V[c] = vadd + (P.vazi[g] - mean);
+    }
+    // input halo of the segment ends (tiled mode): two cells left of lane 0, two right of lane 63
+    double hS[2] = {1.0, 1.0}, hW[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}}, hV = 0.0;
+    if (edge_l || edge_r) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int g = row + wrap(edge_l ? a - 2 + h : a + 64 * C + h);
+            const double s = in.sig[g];
+            const double rs = fast_rcp(s);
+            hS[h] = s;
+            hW[0][h] = in.rmp[g] * rs;
+            hW[1][h] = in.rmm[g] * rs;
+            hW[2][h] = in.lp[g] * rs;
+            hW[3][h] = in.lm[g] * rs;
+            hW[4][h] = ADI ? in.e[g] * rs : 0.0;
+            if (h == 0)
+                hV = vadd + (P.vazi[g] - mean);
+        }
+    }
+    const double dxtheta = P.dphi * P.Rmed[i];
+    const double invdxtheta = 1.0 / dxtheta;
+    const double dxrad = (P.Rsup[i] - P.Rinf[i]) * dt;
+    const double invsurf = P.InvSurf[i];
+
+    // ext[0..C+3] = {left2, own C, right2} of an array whose own part is x[]
+#define THETA_EXT(ext, x, eh0, eh1, first_pass)                                   \
+    {                                                                             \
+        const double l0 = __shfl(x[C - 2], lsrc_l, 64), l1 = __shfl(x[C - 1], lsrc_l, 64); \
+        const double r0 = __shfl(x[0], lsrc_r, 64), r1 = __shfl(x[1], lsrc_r, 64); \
+        ext[0] = (edge_l) ? ((first_pass) ? eh0 : x[0]) : l0;                     \
+        ext[1] = (edge_l) ? ((first_pass) ? eh1 : x[1]) : l1;                     \
+        _Pragma("unroll") for (int c = 0; c < C; ++c) ext[2 + c] = x[c];          \
+        ext[C + 2] = (edge_r) ? ((first_pass) ? eh0 : x[C - 2]) : r0;             \
+        ext[C + 3] = (edge_r) ? ((first_pass) ? eh1 : x[C - 1]) : r1;             \
+    }
+    // ComputeStarTheta (:416-466) on an extended array: limited slope of cell m-1 in dq[m],
+    // then the upwind state at interfaces 0..C (interface k lies between ext[k+1] and ext[k+2]).
+    // UNI: the velocity is uniform along the ring (second pass), the upwind side is a scalar.
+#define THETA_STARS(st, ext, UNI, uni_up)                                                     \
+    {                                                                                         \
+        double dq[C + 2];                                                                     \
+        _Pragma("unroll") for (int m = 0; m < C + 2; ++m)                                     \
+        {                                                                                     \
+            if (!(UNI) || ((uni_up) ? (m <= C) : (m >= 1)))                                   \
+                dq[m] = 0.5 * limiter(P.limiter, ext[m + 2] - ext[m + 1], ext[m + 1] - ext[m]) * invdxtheta; \
+            else                                                                              \
+                dq[m] = 0.0;                                                                  \
+        }                                                                                     \
+        _Pragma("unroll") for (int k = 0; k <= C; ++k)                                        \
+        {                                                                                     \
+            const double xa = up[k] ? ext[k + 1] : ext[k + 2];                                \
+            const double sl = up[k] ? dq[k] : dq[k + 1];                                      \
+            st[k] = xa + dist[k] * sl;                                                        \
+        }                                                                                     \
+    }
+
+    for (int pass = 1; pass <= 2; ++pass) {
+        const bool first = pass == 1;
+        if (!first) {
+            if (!P.fast_transport)
+                break; // NoSplitAdvection: the uniform pass is skipped (:646)
+#pragma unroll
+            for (int c = 0; c <= C; ++c)
+                V[c] = vconst;
+        } else {
+            const double vr = __shfl(V[0], lsrc_r, 64);
+            V[C] = edge_r ? hV : vr;
+        }
+        // per-interface upwind data shared by all quantities
+        bool up[C + 1];
+        double dist[C + 1];
+#pragma unroll
+        for (int k = 0; k <= C; ++k) {
+            const double ksi = V[k] * dt;
+            up[k] = ksi > 0.0;
+            dist[k] = up[k] ? (dxtheta - ksi) : -(dxtheta + ksi);
+        }
+        const bool uni_up = vconst * dt > 0.0;
+        double ext[C + 4], rho[C + 1], rS[C];
+        THETA_EXT(ext, S, hS[0], hS[1], first);
+        if (first) {
+            THETA_STARS(rho, ext, false, false);
+        } else if (uni_up) {
+            THETA_STARS(rho, ext, true, true);
+        } else {
+            THETA_STARS(rho, ext, true, false);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            rS[c] = fast_rcp(S[c]);
+#define THETA_Q(X, HW)                                                                               \
+        {                                                                                            \
+            double W[C], we[C + 4], qs[C + 1], fl[C + 1];                                            \
+            _Pragma("unroll") for (int c = 0; c < C; ++c) W[c] = X[c] * rS[c];                       \
+            THETA_EXT(we, W, HW[0], HW[1], first);                                                   \
+            if (first) {                                                                             \
+                THETA_STARS(qs, we, false, false);                                                   \
+            } else if (uni_up) {                                                                     \
+                THETA_STARS(qs, we, true, true);                                                     \
+            } else {                                                                                 \
+                THETA_STARS(qs, we, true, false);                                                    \
+            }                                                                                        \
+            _Pragma("unroll") for (int k = 0; k <= C; ++k) fl[k] = dxrad * qs[k] * rho[k] * V[k];    \
+            _Pragma("unroll") for (int c = 0; c < C; ++c)                                            \
+            {                                                                                        \
+                double varq = fl[c];                                                                 \
+                varq -= fl[c + 1];                                                                   \
+                X[c] += varq * invsurf;                                                              \
+            }                                                                                        \
+        }
+        THETA_Q(Q[0], hW[0]);
+        THETA_Q(Q[1], hW[1]);
+        THETA_Q(Q[2], hW[2]);
+        THETA_Q(Q[3], hW[3]);
+        if (ADI)
+            THETA_Q(E, hW[4]);
+        {
+            double fl[C + 1];
+#pragma unroll
+            for (int k = 0; k <= C; ++k)
+                fl[k] = dxrad * 1.0 * rho[k] * V[k];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                double varq = fl[c];
+                varq -= fl[c + 1];
+                S[c] += varq * invsurf;
+            }
+        }
+#undef THETA_Q
+    }
+#undef THETA_STARS
+#undef THETA_EXT
+    // AdvectSHIFT (:238-268): cell j lands in j + Nshift (Nshift folded into [0, nphi) once)
+    int nshift = P.nshift[i] % nphi;
+    nshift = nshift < 0 ? nshift + nphi : nshift;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int pos = lane * C + c;
+        const bool valid = act && (periodic == 1 || (pos >= 2 && pos < 64 * C - 2));
+        if (valid) {
+            const int g = row + wrap(idx[c] + nshift);
+            out.sig[g] = S[c];
+            out.rmp[g] = Q[0][c];
+            out.rmm[g] = Q[1][c];
+            out.lp[g] = Q[2][c];
+            out.lm[g] = Q[3][c];
+            if (ADI)
+                out.e[g] = E[c];
+        }
+    }
+}
+
 // compute_velocities_from_momenta (:498-535) + assure_minimum_value and the
 // temperature floor/ceiling of Transport (:121-131); reads set B, writes the state.
-__global__ void k_velocities(const Dev P)
+template <bool ROWU> __global__ void k_velocities(const Dev P, ThetaSet in, const double *vr_src)
 {
     CELL(0, P.nr);
+    if (i == P.nr - 1) // v_r row Nr is not transported: it keeps its post-boundary value
+        P.vrad[IDX(P.nr, j)] = vr_src[IDX(P.nr, j)];
     const int jp = JPREV;
-    const double s = P.sigB[IDX(i, j)];
+    const double s = in.sig[IDX(i, j)];
     if (i == 0)
         P.vrad[IDX(i, j)] = 0.0;
     else
-        P.vrad[IDX(i, j)] = (P.rmpB[IDX(i - 1, j)] + P.rmmB[IDX(i, j)]) / (P.sigB[IDX(i - 1, j)] + s);
+        P.vrad[IDX(i, j)] = (in.rmp[IDX(i - 1, j)] + in.rmm[IDX(i, j)]) / (in.sig[IDX(i - 1, j)] + s);
     P.vazi[IDX(i, j)] =
-        (P.lpB[IDX(i, jp)] + P.lmB[IDX(i, j)]) / (P.sigB[IDX(i, jp)] + s) * P.InvRmed[i] -
+        (in.lp[IDX(i, jp)] + in.lm[IDX(i, j)]) / (in.sig[IDX(i, jp)] + s) * P.InvRmed[i] -
         P.Rmed[i] * P.omega_frame;
     const double sf = s < P.sigma_floor_abs ? P.sigma_floor_abs : s;
     P.sigma[IDX(i, j)] = sf;
     if (P.adiabatic)
-        P.energy[IDX(i, j)] = clamp_energy(P, P.eB[IDX(i, j)], sf);
+        P.energy[IDX(i, j)] = clamp_energy(P, in.e[IDX(i, j)], sf);
 }
 
 // ---------------------------------------------------------------------------
-// cfl.cpp:185-376 condition_cfl.  k_ring_mean gives <v_phi>; k_cfl_init seeds the
-// running minimum with the shear criterion of rings 0|1 (:207-208); k_cfl_cells adds
-// the per-ring shear limit (:213-220) and the six per-cell limits (:243-328).
-__global__ void k_cfl_init(const Dev P)
-{
-    const double denom = fabs(P.vmean[0] * P.InvRmed[0] - P.vmean[1] * P.InvRmed[1]) + 1.0e-100;
-    const double dt_core = P.cfl * P.dphi / denom;
-    P.clk->cfl_bits = (unsigned long long)__double_as_longlong(dt_core);
-}
-__global__ void k_cfl_cells(const Dev P)
+// cfl.cpp:185-376 condition_cfl.  k_ring_mean gives <v_phi>.  dt_cell = CFL / sqrt(sum of
+// the squared inverse limits) and both sqrt and the quotient are monotone, so
+// min_cells dt_cell == CFL / sqrt(max_cells sum): k_cfl_cells reduces the per-cell sums to one
+// maximum per block (no atomics); k_cfl_final folds the block maxima, applies sqrt and the
+// quotient once, and adds the per-ring FARGO shear limit (:207-220).
+template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = P.first_active + blockIdx.y * blockDim.y + threadIdx.y;
-    double dt_cell = 1.0e300;
+    const int i_ = P.first_active + blockIdx.y * blockDim.y + threadIdx.y;
+    const int i = ROWU ? __builtin_amdgcn_readfirstlane(i_) : i_;
+    double s = 0.0;
     if (j < P.nphi && i < P.active_size) {
         const int jn = JNEXT;
-        const double dxRadial = P.Rsup[i] - P.Rinf[i];
-        const double dxAzimuthal = P.Rmed[i] * P.dphi;
-        const double cell_size = dmin(dxRadial, dxAzimuthal);
+        const double inv_dxr = P.InvDiffRsup[i];        // 1 / (Rsup - Rinf)
+        const double inv_dxa = P.InvRmed[i] * P.invdphi; // 1 / (Rmed dphi)
+        const double inv_cell = dmax(inv_dxr, inv_dxa); // 1 / min(dxRadial, dxAzimuthal)
         const double lf = P.leapfrog ? 0.6 : 1.0;
         const double va = P.vazi[IDX(i, j)];
         const double vres = P.fast_transport ? va - P.vmean[i] : va;
         const double vr0 = P.vrad[IDX(i, j)], vr1 = P.vrad[IDX(i + 1, j)];
-        const double invdt1 = P.soundspeed[IDX(i, j)] / cell_size;
-        const double invdt2 = vr0 / dxRadial;
-        const double invdt3 = vres / dxAzimuthal;
+        const double invdt1 = P.soundspeed[IDX(i, j)] * inv_cell;
+        const double invdt2 = vr0 * inv_dxr;
+        const double invdt3 = vres * inv_dxa;
         const double C2 = P.art_visc_factor * P.art_visc_factor;
         double invdt4;
         if (P.art_visc == FCPT_ARTVISC_SN) {
@@ -829,7 +1350,7 @@ __global__ void k_cfl_cells(const Dev P)
             double dvAzimuthal = P.vazi[IDX(i, jn)] - va;
             dvRadial = dvRadial > 0.0 ? 0.0 : -dvRadial;
             dvAzimuthal = dvAzimuthal > 0.0 ? 0.0 : -dvAzimuthal;
-            invdt4 = 4.0 * C2 * dmax(dvRadial / dxRadial, dvAzimuthal / dxAzimuthal) * lf;
+            invdt4 = 4.0 * C2 * dmax(dvRadial * inv_dxr, dvAzimuthal * inv_dxa) * lf;
         } else { // the TW formula is also used for ArtificialViscosity: None (cfl.cpp:292)
             const double eps_rr = (vr1 - vr0) * P.InvDiffRsup[i];
             const double eps_pp =
@@ -837,31 +1358,57 @@ __global__ void k_cfl_cells(const Dev P)
             const double mdiv_V = -dmin(eps_rr + eps_pp, 0.0);
             invdt4 = 4.0 * C2 * mdiv_V * lf;
         }
-        const double invdt5 = 4.0 * P.viscosity[IDX(i, j)] / (cell_size * cell_size) * lf;
+        const double invdt5 = 4.0 * P.viscosity[IDX(i, j)] * (inv_cell * inv_cell) * lf;
         double invdt6 = 0.0;
         if (P.adiabatic) {
             const double inv_limit = 1.0 / P.heating_cooling_cfl_limit;
             invdt6 = inv_limit * fabs((P.qplus[IDX(i, j)] - P.qminus[IDX(i, j)]) / P.energy[IDX(i, j)]) * lf;
         }
-        dt_cell = P.cfl / sqrt(invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 +
-                               invdt5 * invdt5 + invdt6 * invdt6);
-        if (j == 0) {
-            const double denom = fabs(P.vmean[i] * P.InvRmed[i] - P.vmean[i + 1] * P.InvRmed[i + 1]) + 1.0e-100;
-            dt_cell = dmin(dt_cell, P.cfl * P.dphi / denom);
-        }
+        s = invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 + invdt5 * invdt5 +
+            invdt6 * invdt6;
     }
-    // min over the block: wavefront shuffles, then LDS across the 4 waves
     for (int off = 32; off > 0; off >>= 1)
-        dt_cell = dmin(dt_cell, __shfl_down(dt_cell, off, 64));
+        s = dmax(s, __shfl_down(s, off, 64));
     __shared__ double s_w[4];
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     if ((tid & 63) == 0)
-        s_w[tid >> 6] = dt_cell;
+        s_w[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) {
-        const double m = dmin(dmin(s_w[0], s_w[1]), dmin(s_w[2], s_w[3]));
-        // positive doubles order like their bit patterns
-        atomicMin(&P.clk->cfl_bits, (unsigned long long)__double_as_longlong(m));
+    if (tid == 0)
+        part[blockIdx.y * gridDim.x + blockIdx.x] = dmax(dmax(s_w[0], s_w[1]), dmax(s_w[2], s_w[3]));
+}
+__global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *part, int nparts)
+{
+    double smax = 0.0;
+    for (int n = threadIdx.x; n < nparts; n += blockDim.x)
+        smax = dmax(smax, part[n]);
+    // FARGO shear limit, rings 0|1 (:207-208) and the active rings (:213-220)
+    double dt = 1.0e300;
+    for (int n = threadIdx.x; n < P.active_size; n += blockDim.x) {
+        if (n == 0 || n >= P.first_active) {
+            const double denom = fabs(P.vmean[n] * P.InvRmed[n] - P.vmean[n + 1] * P.InvRmed[n + 1]) + 1.0e-100;
+            dt = dmin(dt, P.cfl * P.dphi / denom);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        smax = dmax(smax, __shfl_down(smax, off, 64));
+        dt = dmin(dt, __shfl_down(dt, off, 64));
+    }
+    __shared__ double s_s[16], s_d[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        s_s[wave] = smax;
+        s_d[wave] = dt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            smax = dmax(smax, s_s[w]);
+            dt = dmin(dt, s_d[w]);
+        }
+        if (nparts > 0)
+            dt = dmin(dt, P.cfl / sqrt(smax));
+        P.clk->cfl_bits = (unsigned long long)__double_as_longlong(dt);
     }
 }
 
@@ -892,7 +1439,7 @@ const char *const kKernelNames[KID_COUNT] = {
     "k_sn_q", "k_sn_e", "k_sn_vr", "k_sn_va", "k_temperature_range", "k_adi_cs_h", "k_iso_cs_h",
     "k_viscosity", "k_pressure", "k_temperature", "k_stress_diag", "k_stress_rphi", "k_visc_va",
     "k_visc_vr", "k_qplus_qminus", "k_substep3", "k_boundary", "k_damping", "k_transport_radial",
-    "k_ring_mean", "k_transport_theta1", "k_transport_theta2", "k_velocities", "k_cfl_init",
+    "k_ring_mean", "k_transport_theta1", "k_transport_theta2", "k_velocities", "k_cfl_final",
     "k_cfl_cells", "k_clock"};
 
 thread_local Profiler *g_prof = nullptr;
@@ -929,7 +1476,20 @@ void Profiler::end(int id, hipStream_t st)
     do {                                                                             \
         if ((nrows) > 0) {                                                           \
             const Launch2D l = launch2d((nrows), P.nphi);                            \
-            KLAUNCH(id, kernel, l.grid, l.block, __VA_ARGS__);                       \
+            if (l.block.x >= 64)                                                     \
+                KLAUNCH(id, (kernel<true>), l.grid, l.block, __VA_ARGS__);           \
+            else                                                                     \
+                KLAUNCH(id, (kernel<false>), l.grid, l.block, __VA_ARGS__);          \
+        }                                                                            \
+    } while (0)
+#define LAUNCH2D_T(id, kernel, targ, nrows, ...)                                     \
+    do {                                                                             \
+        if ((nrows) > 0) {                                                           \
+            const Launch2D l = launch2d((nrows), P.nphi);                            \
+            if (l.block.x >= 64)                                                     \
+                KLAUNCH(id, (kernel<targ, true>), l.grid, l.block, __VA_ARGS__);     \
+            else                                                                     \
+                KLAUNCH(id, (kernel<targ, false>), l.grid, l.block, __VA_ARGS__);    \
         }                                                                            \
     } while (0)
 
@@ -978,6 +1538,20 @@ void launch_iso_cs_h(const Dev &P, const double *cs_ring, hipStream_t st)
     LAUNCH2D(KID_ISO_CS_H, k_iso_cs_h, P.nr, P, cs_ring);
 }
 
+void launch_source_fused(const Dev &P, hipStream_t st)
+{
+    LAUNCH2D(KID_SOURCE_VR, k_src_fused, P.nr + 1, P);
+    LAUNCH2D(KID_TW_Q, k_av_fused, P.nr + 1, P);
+}
+void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_VR, k_visc_fused, P.nr + 1, P); }
+void launch_substep3_after_fused(const Dev &P, hipStream_t st)
+{
+    // SubStep3 (SourceEuler.cpp:956-1051) with Q+ already evaluated by k_visc_fused
+    LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P);
+    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr - 2, P, 1);
+    LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
+}
+
 void launch_stress(const Dev &P, hipStream_t st)
 {
     LAUNCH2D(KID_STRESS_DIAG, k_stress_diag, P.nr, P);
@@ -1017,18 +1591,60 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
             r.redge, r.tau, is_density);
 }
 
-void launch_transport(const Dev &P, hipStream_t st)
+void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
 {
+    // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     // Transport, TransportEuler.cpp:112-136
-    LAUNCH2D(KID_TRANSPORT_RADIAL, k_transport_radial, P.nr, P);
+    {
+        const Launch2D l = launch2d((P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS, P.nphi);
+        if (l.block.x >= 64)
+            KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<true>, l.grid, l.block, P);
+        else
+            KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, l.grid, l.block, P);
+    }
     KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(256), P, 1);
     ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     ThetaOut outA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
     ThetaSet inA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
     ThetaOut outB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
-    LAUNCH2D(KID_THETA1, k_transport_theta<1>, P.nr, P, inB, outA);
-    LAUNCH2D(KID_THETA2, k_transport_theta<2>, P.nr, P, inA, outB);
-    LAUNCH2D(KID_VELOCITIES, k_velocities, P.nr, P);
+    // fused azimuthal sweep when a lane-chunk size fits the ring, else the two-pass kernels
+    int C = 0, periodic = 0;
+    for (int c : {2, 4, 6})
+        if (!C && P.nphi % c == 0 && P.nphi <= 64 * c) {
+            C = c;
+            periodic = 1;
+        }
+    if (!C && P.nphi > 64 * 4)
+        C = 4;
+    if (const char *e = getenv("FCPT_THETA_FUSED")) {
+        if (e[0] == '0')
+            C = 0;
+        if (e[0] == 'x' && !periodic)
+            periodic = 2; // timing experiment only (wrong results): coalesced cell assignment
+    }
+    if (C) {
+        const int tiles = periodic == 1 ? 1 : (P.nphi + (64 * C - 4) - 1) / (64 * C - 4);
+        const int waves = P.nr * tiles;
+        const dim3 grid((waves + 3) / 4), block(256);
+#define FUSED(CC)                                                                                      \
+    if (P.adiabatic)                                                                                   \
+        KLAUNCH(KID_THETA1, (k_transport_theta_fused<CC, true>), grid, block, P, inB, outA, tiles, periodic); \
+    else                                                                                               \
+        KLAUNCH(KID_THETA1, (k_transport_theta_fused<CC, false>), grid, block, P, inB, outA, tiles, periodic);
+        if (C == 2) {
+            FUSED(2)
+        } else if (C == 4) {
+            FUSED(4)
+        } else {
+            FUSED(6)
+        }
+#undef FUSED
+        LAUNCH2D(KID_VELOCITIES, k_velocities, P.nr, W, inA, (const double *)P.vrad);
+    } else {
+        LAUNCH2D_T(KID_THETA1, k_transport_theta, 1, P.nr, P, inB, outA);
+        LAUNCH2D_T(KID_THETA2, k_transport_theta, 2, P.nr, P, inA, outB);
+        LAUNCH2D(KID_VELOCITIES, k_velocities, P.nr, W, inB, (const double *)P.vrad);
+    }
 }
 
 void launch_derived(const Dev &P, hipStream_t st)
@@ -1051,12 +1667,17 @@ void launch_temperature(const Dev &P, hipStream_t st) { LAUNCH2D(KID_TEMPERATURE
 void launch_cfl(const Dev &P, hipStream_t st)
 {
     KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(256), P, 0);
-    KLAUNCH(KID_CFL_INIT, k_cfl_init, dim3(1), dim3(1), P);
     const int nrows = P.active_size - P.first_active;
+    int nparts = 0;
     if (nrows > 0) {
         const Launch2D l = launch2d(nrows, P.nphi);
-        KLAUNCH(KID_CFL_CELLS, k_cfl_cells, l.grid, l.block, P);
+        nparts = (int)(l.grid.x * l.grid.y);
+        if (l.block.x >= 64)
+            KLAUNCH(KID_CFL_CELLS, k_cfl_cells<true>, l.grid, l.block, P, P.cfl_part);
+        else
+            KLAUNCH(KID_CFL_CELLS, k_cfl_cells<false>, l.grid, l.block, P, P.cfl_part);
     }
+    KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, nparts);
 }
 
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st)

@@ -1,0 +1,105 @@
+"""One radial slab per process over torch.distributed (RCCL on MI355X: backend "nccl";
+CPU tests: "gloo").  The two communication points of the path are the reference's:
+
+* cfl.cpp:379          MPI_Allreduce(MIN) of the CFL time step  -> dist.all_reduce(MIN)
+* commbound.cpp:98-182 7 overlap rings of Sigma, v_r, v_phi(, e) with both radial neighbours
+                        -> dist.batch_isend_irecv of one packed buffer per direction
+
+Buffers live where the slab's library keeps its grids: torch CUDA tensors for the HIP
+library (their device addresses are handed to fcpt_exchange_pack/unpack, kernels and RCCL
+share torch's current stream), CPU tensors for host libraries.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import binding as B
+
+
+class DistributedSlab:
+    def __init__(self, ctx: B.Context, device: torch.device | None = None):
+        self.ctx = ctx
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self.device = device or torch.device("cpu")
+        self.on_gpu = self.device.type == "cuda"
+        cnt = ctx.exchange_count()
+        mk = lambda: torch.zeros(cnt, dtype=torch.float64, device=self.device)
+        self.has_inner, self.has_outer = self.rank > 0, self.rank < self.world - 1
+        self.s_in, self.r_in = (mk(), mk()) if self.has_inner else (None, None)
+        self.s_out, self.r_out = (mk(), mk()) if self.has_outer else (None, None)
+        self._dt = torch.zeros(1, dtype=torch.float64, device=self.device)
+        if self.on_gpu:
+            ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _arg(self, t):
+        if t is None:
+            return None
+        return t.data_ptr() if self.on_gpu else t.numpy()
+
+    # cfl.cpp:379
+    def global_cfl(self) -> float:
+        self._dt[0] = self.ctx.cfl()
+        if self.world > 1:
+            dist.all_reduce(self._dt, op=dist.ReduceOp.MIN)
+        return float(self._dt.item())
+
+    def calculate_timestep(self) -> float:
+        return self.ctx.calculate_timestep(self.global_cfl())
+
+    # commbound.cpp:98-182
+    def exchange(self):
+        if self.world == 1:
+            return
+        self.ctx.exchange_pack(self._arg(self.s_in), self._arg(self.s_out))
+        ops = []
+        if self.has_inner:
+            ops += [dist.P2POp(dist.isend, self.s_in, self.rank - 1), dist.P2POp(dist.irecv, self.r_in, self.rank - 1)]
+        if self.has_outer:
+            ops += [dist.P2POp(dist.isend, self.s_out, self.rank + 1), dist.P2POp(dist.irecv, self.r_out, self.rank + 1)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        self.ctx.exchange_unpack(self._arg(self.r_in), self._arg(self.r_out))
+
+    def prepare(self):
+        """main.cpp:117,147 and sim::init (simulation.cpp:462-474)."""
+        self.calculate_timestep()
+        self.exchange()
+        self.ctx.apply_boundary(0.0, False)
+        self.calculate_timestep()
+        self.exchange()
+
+    def step(self, snap: bool = False) -> float:
+        dt = self.calculate_timestep()
+        step_dt = self.ctx.snap_to_monitor(dt) if snap else dt
+        self.ctx.step(step_dt)
+        self.exchange()
+        self.ctx.post(step_dt)
+        return step_dt
+
+    def gather(self):
+        """Global grids on rank 0 with the overlap rings stripped (write2D windows,
+        polargrid.cpp:135-180); other ranks return None."""
+        s = self.ctx.split
+        out = {}
+        for name, f in (("sigma", B.F_SIGMA), ("vrad", B.F_VRAD), ("vazi", B.F_VAZI), ("energy", B.F_ENERGY)):
+            a = self.ctx.download(f)
+            lo = 0 if s.is_first else B.OVERLAP
+            hi = a.shape[0] - (0 if s.is_last else B.OVERLAP)
+            if f == B.F_VRAD and not s.is_last:
+                hi -= 1
+            part = torch.from_numpy(np.ascontiguousarray(a[lo:hi]))
+            if self.world == 1:
+                out[name] = part.numpy()
+                continue
+            sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+            dist.all_gather(sizes, torch.tensor([part.shape[0]], dtype=torch.int64))
+            nmax = max(int(n.item()) for n in sizes)
+            padded = torch.zeros(nmax, part.shape[1], dtype=torch.float64)
+            padded[:part.shape[0]] = part
+            parts = [torch.zeros_like(padded) for _ in sizes]
+            dist.all_gather(parts, padded)  # equal-sized pieces, trimmed below
+            out[name] = torch.cat([p[:int(n.item())] for p, n in zip(parts, sizes)], 0).numpy()
+        return out if self.rank == 0 else None

@@ -57,6 +57,7 @@ struct orc_ctx {
     /* cfl scratch (cfl.cpp:11-12) */
     double *cfl_vmean, *cfl_vres;
     int viscosity_calculated; /* static bool of viscosity::update_viscosity */
+    int big;                  /* grid large enough for OpenMP teams to pay off */
 
     /* bodies */
     int nbodies;
@@ -562,6 +563,7 @@ int orc_create(const fcpt_desc *d, const double *radii, orc_ctx **out)
     }
     c->nr = c->s.nr;
     c->nphi = d->nphi;
+    c->big = (long)c->nr * c->nphi >= 32768;
     c->dphi = 2.0 * M_PI / (double)c->nphi; /* Interpret.cpp:230-231 */
     c->invdphi = (double)c->nphi / (2.0 * M_PI);
     const size_t ng = (size_t)d->nr_global + FCPT_GEOM_PAD + 1;
@@ -759,7 +761,7 @@ static void compute_sound_speed(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
     const fcpt_desc *d = &c->d;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             if (d->eos == FCPT_EOS_IDEAL) {
@@ -777,7 +779,7 @@ static void compute_sound_speed(orc_ctx *c)
 static void compute_scale_height(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr) {
         const double inv_omega_kepler = 1.0 / omega_kepler(c, c->Rmed[nr]);
         for (int naz = 0; naz < Nphi; ++naz) {
@@ -793,7 +795,7 @@ static void compute_scale_height(orc_ctx *c)
 static void compute_pressure(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             if (c->d.eos == FCPT_EOS_IDEAL)
@@ -810,7 +812,7 @@ static void compute_temperature(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
     const double Rgas = c->d.Rgas;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             if (c->d.eos == FCPT_EOS_IDEAL) {
@@ -828,7 +830,7 @@ static void update_viscosity(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
     if (c->d.viscous_alpha > 0) {
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
         for (int nr = 0; nr < Nr; ++nr)
             for (int naz = 0; naz < Nphi; ++naz) {
                 const double alpha = c->d.viscous_alpha;
@@ -859,7 +861,7 @@ static void assure_temperature_range(orc_ctx *c)
     const int Nr = c->nr, Nphi = c->nphi;
     const double Tmin = c->d.minimum_temperature, Tmax = c->d.maximum_temperature;
     const double mu = c->d.mu, g = c->d.adiabatic_index, R = c->d.Rgas;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const double rho = c->sigma[IDX(c, nr, naz)];
@@ -877,7 +879,7 @@ static void assure_temperature_range(orc_ctx *c)
 static void calculate_potential(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const double x = c->Rmed[nr] * cos(c->dphi * (double)naz); /* SideEuler.cpp:60-63 */
@@ -1164,7 +1166,7 @@ static void momentum_update_radial(orc_ctx *c, double dt)
 {
     const int Nphi = c->nphi;
     const double OmegaF = c->d.omega_frame;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = c->s.one_no_ghost_vr; nr < c->s.maxmo_no_ghost_vr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             double gradp = 2.0 / (c->sigma[IDX(c, nr, naz)] + c->sigma[IDX(c, nr - 1, naz)]);
@@ -1185,7 +1187,7 @@ static void momentum_update_radial(orc_ctx *c, double dt)
 static void momentum_update_azimuthal(orc_ctx *c, double dt)
 {
     const int Nphi = c->nphi;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = c->s.zero_no_ghost; nr < c->s.max_no_ghost; ++nr) {
         const double invdxtheta = 2.0 / (c->dphi * (c->Rsup[nr] + c->Rinf[nr]));
         for (int naz = 0; naz < Nphi; ++naz) {
@@ -1206,7 +1208,7 @@ static void compression_heating(orc_ctx *c, double dt)
         return;
     const int Nr = c->nr - 1, Nphi = c->nphi;
     const double gamma = c->d.adiabatic_index;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const int naz_next = (naz == Nphi - 1 ? 0 : naz + 1);
@@ -1225,7 +1227,7 @@ static void artificial_viscosity_TW(orc_ctx *c, double dt)
     const int Nr = c->nr, Nphi = c->nphi;
     const int adi = c->d.eos == FCPT_EOS_IDEAL;
     const double C = c->d.artificial_viscosity_factor;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const int naz_next = naz == Nphi - 1 ? 0 : naz + 1;
@@ -1257,7 +1259,7 @@ static void artificial_viscosity_TW(orc_ctx *c, double dt)
                 }
             }
         }
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 1; nr < Nr - 1; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const int naz_prev = (naz == 0 ? Nphi - 1 : naz - 1);
@@ -1266,7 +1268,7 @@ static void artificial_viscosity_TW(orc_ctx *c, double dt)
                                (c->qphi[IDX(c, nr, naz)] - c->qphi[IDX(c, nr, naz_prev)]) * c->invdphi;
             c->vazi[IDX(c, nr, naz)] += dVp;
         }
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = c->s.one_no_ghost_vr; nr < c->s.maxmo_no_ghost_vr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const double sigma_r_avg = 0.5 * (c->sigma[IDX(c, nr, naz)] + c->sigma[IDX(c, nr - 1, naz)]);
@@ -1285,7 +1287,7 @@ static void artificial_viscosity_SN(orc_ctx *c, double dt)
         return;
     const int Nr = c->nr, Nphi = c->nphi;
     const double C = c->d.artificial_viscosity_factor;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const double dv_r = c->vrad[IDX(c, nr + 1, naz)] - c->vrad[IDX(c, nr, naz)];
@@ -1301,7 +1303,7 @@ static void artificial_viscosity_SN(orc_ctx *c, double dt)
                 c->qphi[IDX(c, nr, naz)] = 0.0;
         }
     if (c->d.eos == FCPT_EOS_IDEAL && c->d.artificial_viscosity_dissipation) {
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
         for (int nr = c->s.zero_no_ghost; nr < c->s.max_no_ghost; ++nr) {
             const double dxtheta = c->dphi * c->Rmed[nr];
             const double invdxtheta = 1.0 / dxtheta;
@@ -1315,14 +1317,14 @@ static void artificial_viscosity_SN(orc_ctx *c, double dt)
             }
         }
     }
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = c->s.one_no_ghost_vr; nr < c->s.maxmo_no_ghost_vr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz)
             c->vrad[IDX(c, nr, naz)] =
                 c->vrad[IDX(c, nr, naz)] -
                 dt * 2.0 / (c->sigma[IDX(c, nr, naz)] + c->sigma[IDX(c, nr - 1, naz)]) *
                     (c->qr[IDX(c, nr, naz)] - c->qr[IDX(c, nr - 1, naz)]) * c->InvDiffRmed[nr];
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = c->s.zero_no_ghost; nr < c->s.max_no_ghost; ++nr) {
         const double dxtheta = c->dphi * c->Rmed[nr];
         const double invdxtheta = 1.0 / dxtheta;
@@ -1360,7 +1362,7 @@ static void recalculate_viscosity(orc_ctx *c)
 static void compute_viscous_stress_tensor(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const int naz_next = (naz == Nphi - 1 ? 0 : naz + 1);
@@ -1369,7 +1371,7 @@ static void compute_viscous_stress_tensor(orc_ctx *c)
                     c->InvDiffRsupRb[nr] +
                 (c->vazi[IDX(c, nr, naz_next)] - c->vazi[IDX(c, nr, naz)]) * c->invdphi * c->InvRmed[nr];
         }
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const double drr =
@@ -1377,7 +1379,7 @@ static void compute_viscous_stress_tensor(orc_ctx *c)
             c->trr[IDX(c, nr, naz)] = 2.0 * c->viscosity[IDX(c, nr, naz)] * c->sigma[IDX(c, nr, naz)] *
                                       (drr - 1.0 / 3.0 * c->divv[IDX(c, nr, naz)]);
         }
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const int naz_next = (naz == Nphi - 1 ? 0 : naz + 1);
@@ -1388,7 +1390,7 @@ static void compute_viscous_stress_tensor(orc_ctx *c)
             const double sigma = c->sigma[IDX(c, nr, naz)];
             c->tpp[IDX(c, nr, naz)] = 2.0 * nu * sigma * (dpp - 1.0 / 3.0 * c->divv[IDX(c, nr, naz)]);
         }
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 1; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const int naz_prev = (naz == 0 ? Nphi - 1 : naz - 1);
@@ -1410,7 +1412,7 @@ static void compute_viscous_stress_tensor(orc_ctx *c)
 static void update_velocities_with_viscosity(orc_ctx *c, double dt)
 {
     const int Nr = c->nr, Nphi = c->nphi;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 1; nr < Nr - 1; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const int naz_prev = (naz == 0 ? Nphi - 1 : naz - 1);
@@ -1423,7 +1425,7 @@ static void update_velocities_with_viscosity(orc_ctx *c, double dt)
                  (c->tpp[IDX(c, nr, naz)] - c->tpp[IDX(c, nr, naz_prev)]) * c->invdphi);
             c->vazi[IDX(c, nr, naz)] += dVp;
         }
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = c->s.one_no_ghost_vr; nr < c->s.maxmo_no_ghost_vr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const int naz_next = (naz == Nphi - 1 ? 0 : naz + 1);
@@ -1449,7 +1451,7 @@ static void calculate_qplus(orc_ctx *c)
     memset(c->qplus, 0, sizeof(double) * (size_t)c->nr * c->nphi);
     if (!c->d.heating_viscous)
         return;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 1; nr < Nr_m1; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             if (c->viscosity[IDX(c, nr, naz)] != 0.0) {
@@ -1483,7 +1485,7 @@ static void substep3(orc_ctx *c, double dt)
     compute_temperature(c);
     calculate_qminus(c);
     calculate_qplus(c);
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 1; nr < Nr - 1; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const double H = c->scale_height[IDX(c, nr, naz)];
@@ -1554,7 +1556,7 @@ static void compute_momenta_from_velocities(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
     const double OmegaF = c->d.omega_frame;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const double S = c->sigma[IDX(c, nr, naz)];
@@ -1571,7 +1573,7 @@ static void compute_momenta_from_velocities(orc_ctx *c)
 static void compute_velocities_from_momenta(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const int nm = (naz == 0 ? (Nphi - 1) : naz - 1);
@@ -1592,7 +1594,7 @@ static void compute_star_radial(orc_ctx *c, const double *Qbase, const double *V
 {
     const int Nr = c->nr, Nphi = c->nphi;
     double *dq = c->dq;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const size_t cell = IDX(c, nr, naz);
@@ -1604,7 +1606,7 @@ static void compute_star_radial(orc_ctx *c, const double *Qbase, const double *V
                 dq[cell] = flux_limiter(c, dqp, dqm);
             }
         }
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 1; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const size_t cell = IDX(c, nr, naz);
@@ -1623,7 +1625,7 @@ static void compute_star_radial(orc_ctx *c, const double *Qbase, const double *V
 static void divise(const orc_ctx *c, const double *num, const double *den, double *res)
 {
     const size_t n = (size_t)c->nr * c->nphi;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (size_t i = 0; i < n; ++i)
         res[i] = num[i] / den[i];
 }
@@ -1633,7 +1635,7 @@ static void VanLeerRadial(orc_ctx *c, const double *VRadial, double *Qbase, doub
     const int Nr = c->nr, Nphi = c->nphi;
     divise(c, Qbase, c->density_int, c->work);
     compute_star_radial(c, c->work, VRadial, c->qrstar, dt);
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
             const size_t cell = IDX(c, nr, naz);
@@ -1665,7 +1667,7 @@ static void ComputeStarTheta(orc_ctx *c, const double *Qbase, const double *VAzi
 {
     const int Nr = c->nr, Nphi = c->nphi;
     double *dq = c->dq;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr) {
         const double dxtheta = c->dphi * c->Rmed[nr];
         const double invdxtheta = 1.0 / dxtheta;
@@ -1681,7 +1683,7 @@ static void ComputeStarTheta(orc_ctx *c, const double *Qbase, const double *VAzi
             dq[cell] = 0.5 * flux_limiter(c, dqp, dqm) * invdxtheta;
         }
     }
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr) {
         const double dxtheta = c->dphi * c->Rmed[nr];
         for (int naz = 0; naz < Nphi; ++naz) {
@@ -1704,7 +1706,7 @@ static void VanLeerTheta(orc_ctx *c, const double *VAzimuthal, double *Qbase, do
     const int Nr = c->nr, Nphi = c->nphi;
     divise(c, Qbase, c->density_int, c->work);
     ComputeStarTheta(c, c->work, VAzimuthal, c->qrstar, dt);
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr) {
         const double dxrad = (c->Rsup[nr] - c->Rinf[nr]) * dt;
         const double invsurf = c->InvSurf[nr];
@@ -1739,7 +1741,7 @@ static void QuantitiesAdvection(orc_ctx *c, const double *VAzimuthal, double dt,
 static void AdvectSHIFT(orc_ctx *c, double *val)
 {
     const int nr = c->nr, ns = c->nphi;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int i = 0; i < nr; i++)
         for (int j = 0; j < ns; j++) {
             int ji = j - c->nshift[i];
@@ -1757,7 +1759,7 @@ static void OneWindTheta(orc_ctx *c, double dt)
     const int Nr = c->nr, Nphi = c->nphi;
     const int adi = c->d.eos == FCPT_EOS_IDEAL;
     /* compute_average_azimuthal_velocity */
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr) {
         double sum = 0.0;
         for (int naz = 0; naz < Nphi; ++naz)
@@ -1765,13 +1767,13 @@ static void OneWindTheta(orc_ctx *c, double dt)
         c->vmean[nr] = sum / (double)Nphi;
     }
     /* compute_residual_velocity */
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int nr = 0; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz)
             c->vres[IDX(c, nr, naz)] = c->vazi[IDX(c, nr, naz)] - c->vmean[nr];
     /* ComputeConstantResidual */
     const double invdt = 1.0 / dt;
-#pragma omp parallel for
+#pragma omp parallel for if (c->big)
     for (int i = 0; i < Nr; i++) {
         const double Ntilde = c->vmean[i] * c->InvRmed[i] * dt * c->invdphi;
         const double Nround = floor(Ntilde + 0.5);

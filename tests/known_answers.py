@@ -1,0 +1,47 @@
+"""The reference's own known-answer checks, restated (they are pure post-processing):
+test/shockTube/check_results.py:93-127 and test/spreading_ring/calc_deviation.py:17-66."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+from scipy import integrate, interpolate
+from scipy.special import iv
+
+from fargocpt_amd import binding as B
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SHOCKTUBE_THRESHOLDS = {"vrad": 0.0153, "Sigma": 0.0073, "Temperature": 0.016, "energy": 0.014}
+SPREADING_RING_THRESHOLD = 0.007
+
+
+def shocktube_deviations(lib, d, ctx):
+    an = np.loadtxt(os.path.join(GOLDEN, "shocktube_analytic_shock.dat"), skiprows=2)
+    r12 = lib.radii(d)[:d.nr_global + 1]
+    r1 = 0.5 * (r12[1:] + r12[:-1]) - r12[0]
+    st = ctx.state()
+    v = st["vrad"].mean(1)
+    q = {"vrad": 0.5 * (v[1:] + v[:-1]), "Sigma": st["sigma"].mean(1),
+         "Temperature": ctx.download(B.F_TEMPERATURE).mean(1), "energy": st["energy"].mean(1)}
+    key = {"vrad": 0, "Sigma": 1, "Temperature": 2, "energy": 3}
+    inds = (r1 >= 0) & (r1 <= 1)
+    out = {}
+    for name, data in q.items():
+        y = an[:, key[name] + 2]
+        if name == "energy":
+            y = an[:, 4] * an[:, 3] / (1.4 - 1)
+        spl = interpolate.InterpolatedUnivariateSpline(an[:, 1], y)
+        out[name] = float(integrate.simpson(np.abs(data[inds] - spl(r1[inds])), x=r1[inds]))
+    return out
+
+
+def spreading_ring_deviation(lib, d, ctx):
+    radii = lib.radii(d)[:d.nr_global + 1]
+    Rinf, Rsup = radii[:-1], radii[1:]
+    rc = 2.0 / 3.0 * (Rsup ** 3 - Rinf ** 3) / (Rsup ** 2 - Rinf ** 2)
+    sigma = ctx.download(B.F_SIGMA).mean(1)
+    t = ctx.clock.time
+    nu, tau0 = 4.77e-5, 0.016
+    tau = 12 * nu * t + tau0
+    theo = 1.0 / np.pi / tau / rc ** 0.25 * iv(0.25, 2.0 * rc / tau) * np.exp(-(1 + rc ** 2) / tau)
+    return float(np.mean(np.abs(sigma / theo - 1)))

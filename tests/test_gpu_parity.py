@@ -66,6 +66,23 @@ def test_two_slabs_match_one(product, oracle):
     _check(run_pair(product, oracle, d, 30, nslabs=(2, 1)), ("sigma", "vrad", "vazi"))
 
 
+def test_tiled_azimuthal_sweep_32x640(product, oracle):
+    """Nphi > 384 takes the tiled mode of the fused azimuthal kernel (segments of 256 cells)."""
+    d = setups.planet_disk(product, 32, 640)
+    _check(run_pair(product, oracle, d, 25, bodies=setups.jupiter_bodies(d)), ("sigma", "vrad", "vazi"))
+    d = setups.planet_disk(product, 32, 640, adiabatic=True)
+    _check(run_pair(product, oracle, d, 25), ("sigma", "vrad", "vazi", "energy"))
+
+
+def test_unfused_paths_agree(product, oracle, monkeypatch):
+    """The per-loop kernels (FCPT_FUSED_SOURCE=0, FCPT_THETA_FUSED=0) stay available as a
+    cross-check of the fused ones."""
+    monkeypatch.setenv("FCPT_FUSED_SOURCE", "0")
+    monkeypatch.setenv("FCPT_THETA_FUSED", "0")
+    d = setups.planet_disk(product, 48, 96, adiabatic=True)
+    _check(run_pair(product, oracle, d, 20), ("sigma", "vrad", "vazi", "energy"))
+
+
 def test_mc_limiter_and_standard_transport(product, oracle):
     d = setups.planet_disk(product, 48, 64)
     d.flux_limiter = B.LIMITER_MC

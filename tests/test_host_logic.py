@@ -1,0 +1,111 @@
+"""Host-side logic of the product library (no GPU): ABI surface, descriptor defaults, radial
+split, grid construction and initial conditions, checked against the oracle's restatement."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fargocpt_amd
+from fargocpt_amd import binding as B, setups
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(product):
+    hdr = open(os.path.join(ROOT, "include", "fargocpt_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(fcpt_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    missing = [s for s in declared if not hasattr(product.cdll, s)]
+    assert not missing, missing
+
+
+def test_desc_struct_matches_header(product):
+    d = product.desc_default()
+    assert d.struct_size == ctypes.sizeof(B.Desc)
+    assert d.abi_version == B.ABI_VERSION
+    assert d.cfl == 0.5 and d.cfl_max_var == 1.1 and d.first_dt == 1e-9
+    assert d.artificial_viscosity == B.ARTVISC_SN and d.fast_transport == 1
+    assert d.G == 1.0 and d.Rgas == 1.0
+    assert 1e4 < d.c_light < 1.1e4  # c in au / (yr / 2 pi)
+
+
+def test_create_without_gpu_fails_loudly(product):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    d = setups.planet_disk(product, 32, 32)
+    with pytest.raises(B.FcptError, match="FCPT_ENODEV"):
+        product.create(d, product.radii(d))
+
+
+def test_bad_descriptor_rejected(product):
+    d = setups.planet_disk(product, 32, 32)
+    d.struct_size = 8
+    with pytest.raises(B.FcptError):
+        product.create(d, np.zeros(64))
+
+
+@pytest.mark.parametrize("nr,nranks", [(128, 1), (128, 2), (130, 4), (2048, 8)])
+def test_split_domain(product, oracle, nr, nranks):
+    """src/split.cpp:34-88"""
+    covered = []
+    for rank in range(nranks):
+        d = setups.planet_disk(product, nr, 64)
+        d.rank, d.nranks = rank, nranks
+        s, so = product.split_domain(d), oracle.split_domain(d)
+        for f, _ in B.Split._fields_:
+            assert getattr(s, f) == getattr(so, f), f
+        assert s.nr == s.imax - s.imin + 1
+        lo = s.imin + s.zero_or_active
+        hi = s.imin + s.max_or_active
+        covered.append((lo, hi))
+        if nranks == 1:
+            assert (s.zero_no_ghost, s.one_no_ghost_vr, s.max_no_ghost, s.maxmo_no_ghost_vr) == (1, 2, nr - 1, nr - 1)
+            assert (s.radial_first_active, s.radial_active_size) == (1, nr - 1)
+    assert covered[0][0] == 0 and covered[-1][1] == nr
+    for (a, b), (c, e) in zip(covered, covered[1:]):
+        assert b == c  # write windows tile the global grid (polargrid.cpp:150-172)
+
+
+def test_split_too_narrow(product):
+    d = setups.planet_disk(product, 40, 64)
+    d.rank, d.nranks = 0, 4  # 10 rings per slab < 2 * CPUOVERLAP
+    with pytest.raises(B.FcptError, match="FCPT_ESPLIT"):
+        product.split_domain(d)
+
+
+@pytest.mark.parametrize("spacing", [B.SPACING_ARITHMETIC, B.SPACING_LOGARITHMIC, B.SPACING_EXPONENTIAL])
+def test_radii(product, oracle, spacing):
+    """src/init.cpp:92-145: Radii[1] = Rmin, Radii[N-1] = Rmax, one ghost cell outside each."""
+    d = setups.planet_disk(product, 64, 32)
+    d.radial_spacing = spacing
+    r, ro = product.radii(d), oracle.radii(d)
+    assert np.array_equal(r, ro)
+    assert r[1] == pytest.approx(d.rmin, rel=1e-15) and r[d.nr_global - 1] == pytest.approx(d.rmax, rel=1e-13)
+    assert np.all(np.diff(r) > 0)
+
+
+@pytest.mark.parametrize("name", ["planet_iso", "planet_adi", "ring", "shock"])
+def test_initial_fields_match_oracle(product, oracle, name):
+    d = {"planet_iso": lambda: setups.planet_disk(product, 48, 16),
+         "planet_adi": lambda: setups.planet_disk(product, 48, 16, adiabatic=True),
+         "ring": lambda: setups.spreading_ring(product, 64, 4),
+         "shock": lambda: setups.shocktube(product, 64, 4)}[name]()
+    radii = product.radii(d)
+    d1, d2 = d.copy(), d.copy()
+    f1, f2 = product.initial_fields(d1, radii), oracle.initial_fields(d2, radii)
+    assert d1.sigma0 == pytest.approx(d2.sigma0, rel=1e-13)
+    for a, b, n in zip(f1, f2, ("sigma", "vrad", "vazi", "energy")):
+        # std::cyl_bessel_i vs the oracle's series differ at the 1e-15 level for the ring
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=0, err_msg=n)
+    if name == "shock":
+        assert set(np.unique(f1[0])) == {0.125, 1.0}
+    if name == "ring":
+        assert abs(d1.sigma0 / d.sigma0 - 1) < 0.05  # SetSigma0 renormalisation (init.cpp:1150-1185)
+
+
+def test_kernel_name_table(product):
+    names = product.kernel_names()
+    assert "k_transport_radial" in names and len(set(names)) == len(names)
