@@ -37,6 +37,7 @@ struct fcpt_ctx {
     Profiler prof;
     bool profiling = false;
     bool fused_source = true;
+    bool march_source = true;
 };
 
 namespace {
@@ -129,14 +130,14 @@ void apply_boundary_view(fcpt_ctx *c, const Dev &P, bool final)
     if (final && c->d.damping) {
         // damping.cpp:754-774, order of damping_vector: vrad, vaz, sigma, energy
         for (int o = 0; o < 2; ++o)
-            launch_damping(P, P.vrad, P.vrad0, P.Rinf, c->damp[0][o], 0, c->stream);
+            launch_damping(P, P.vrad, P.vrad0, P.Rinf.p, c->damp[0][o], 0, c->stream);
         for (int o = 0; o < 2; ++o)
-            launch_damping(P, P.vazi, P.vazi0, P.Rmed, c->damp[1][o], 0, c->stream);
+            launch_damping(P, P.vazi, P.vazi0, P.Rmed.p, c->damp[1][o], 0, c->stream);
         for (int o = 0; o < 2; ++o)
-            launch_damping(P, P.sigma, P.sigma0, P.Rmed, c->damp[2][o], 1, c->stream);
+            launch_damping(P, P.sigma, P.sigma0, P.Rmed.p, c->damp[2][o], 1, c->stream);
         if (P.adiabatic)
             for (int o = 0; o < 2; ++o)
-                launch_damping(P, P.energy, P.energy0, P.Rmed, c->damp[3][o], 0, c->stream);
+                launch_damping(P, P.energy, P.energy0, P.Rmed.p, c->damp[3][o], 0, c->stream);
     }
     launch_boundary(P, c->stream);
 }
@@ -171,9 +172,11 @@ void enqueue_step(fcpt_ctx *c)
         c->potential_valid = true;
     }
     if (c->fused_source) {
-        launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
-        launch_recalculate_viscosity(P, st);
-        launch_viscous_fused(P, st);         // (v) -> (v_b)
+        if (!(c->march_source && launch_source_march(P, st))) { // one pass: (v) -> (v_b)
+            launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
+            launch_recalculate_viscosity(P, st);
+            launch_viscous_fused(P, st);         // (v) -> (v_b)
+        }
         if (P.adiabatic)
             launch_substep3_after_fused(P, st);
         Dev Q = P; // view with the post-source velocities
@@ -258,7 +261,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     int rc = FCPT_OK;
 #define UP(field) \
     if (!rc)      \
-        rc = dev_upload(c, &P.field, c->geo.field);
+        rc = dev_upload(c, &P.field.p, c->geo.field);
     UP(Rmed) UP(Rinf) UP(Rsup) UP(Surf) UP(InvRmed) UP(InvRinf) UP(InvSurf) UP(InvDiffRmed)
     UP(InvDiffRsup) UP(InvDiffRsupRb)
 #undef UP
@@ -280,6 +283,20 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     if (!rc)
         rc = dev_upload(c, &csr, cs_ring);
     c->d_cs_ring = const_cast<double *>(csr);
+    P.cs_ring.p = csr;
+    {
+        // isothermal alpha viscosity per ring, exactly as k_iso_cs_h + k_viscosity evaluate it:
+        // H = cs * (1 / Omega_K), nu = alpha * H * cs
+        std::vector<double> nu_ring(nr);
+        for (int i = 0; i < nr; ++i) {
+            const double r = c->geo.Rmed[i];
+            const double inv_omega_kepler = 1.0 / std::sqrt(d->G * d->hydro_center_mass / (r * r * r));
+            const double H = cs_ring[i] * inv_omega_kepler;
+            nu_ring[i] = d->viscous_alpha * H * cs_ring[i];
+        }
+        if (!rc)
+            rc = dev_upload(c, &P.nu_ring.p, nu_ring);
+    }
 
     const size_t ns = (size_t)nr * nphi, nv = (size_t)(nr + 1) * nphi;
 #define AL(field, n) \
@@ -303,6 +320,9 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         fcpt_destroy(c);
         return rc;
     }
+    P.vmean_c.p = P.vmean;
+    P.vconst_c.p = P.vconst;
+    P.nshift_c.p = P.nshift;
     c->grid[FCPT_F_SIGMA] = P.sigma;
     c->grid[FCPT_F_VRAD] = P.vrad;
     c->grid[FCPT_F_VAZI] = P.vazi;
@@ -392,6 +412,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     }
     if (const char *e = getenv("FCPT_FUSED_SOURCE"))
         c->fused_source = e[0] != '0';
+    if (const char *e = getenv("FCPT_MARCH_SOURCE"))
+        c->march_source = e[0] != '0';
     *out = c;
     return FCPT_OK;
 }

@@ -50,14 +50,38 @@ struct DampRange {
     double rlim, redge, tau;
 };
 
+// Read-only per-ring array.  Device reads go through the constant address space, so a
+// wavefront-uniform index becomes a scalar-cache load (s_load) even inside kernels that also
+// store to global memory; plain `const double*` members would be re-read with 64-lane vector
+// loads at full memory latency because the compiler cannot rule out aliasing with the stores.
+// These arrays are written only by hipMemcpy / an earlier kernel, never by the reading kernel.
+struct CArr {
+    const double *p;
+#ifdef __HIPCC__
+    __device__ __forceinline__ double operator[](int i) const
+    {
+        return ((const double __attribute__((address_space(4))) *)p)[i];
+    }
+#endif
+};
+struct CArrI {
+    const int *p;
+#ifdef __HIPCC__
+    __device__ __forceinline__ int operator[](int i) const
+    {
+        return ((const int __attribute__((address_space(4))) *)p)[i];
+    }
+#endif
+};
+
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.
 struct Dev {
     int nr, nphi;
     double dphi, invdphi;
     // geometry
-    const double *Rmed, *Rinf, *Rsup, *Surf, *InvRmed, *InvRinf, *InvSurf, *InvDiffRmed, *InvDiffRsup,
-        *InvDiffRsupRb;
+    CArr Rmed, Rinf, Rsup, Surf, InvRmed, InvRinf, InvSurf, InvDiffRmed, InvDiffRsup, InvDiffRsupRb;
     const double *cosphi, *sinphi; // cos/sin(dphi * j), j < nphi (SideEuler.cpp:60-63)
+    CArr cs_ring, nu_ring; // isothermal sound speed and alpha-viscosity per ring
     // state
     double *sigma, *vrad, *vazi, *energy;
     double *vrad_b, *vazi_b; // intermediate velocities of the fused source step
@@ -73,6 +97,8 @@ struct Dev {
     double *vmean;  // per ring <v_phi>
     double *vconst; // per ring constant residual velocity
     int *nshift;    // per ring integer shift
+    CArr vmean_c, vconst_c; // the same arrays for kernels that only read them
+    CArrI nshift_c;
     double *cfl_part; // per-block maxima of the CFL reduction
     DevClock *clk;
     // split

@@ -44,6 +44,7 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
                     int is_density, hipStream_t st);
 void launch_transport(const Dev &P, const Dev &W, hipStream_t st);
 void launch_source_fused(const Dev &P, hipStream_t st);
+bool launch_source_march(const Dev &P, hipStream_t st);
 void launch_viscous_fused(const Dev &P, hipStream_t st);
 void launch_substep3_after_fused(const Dev &P, hipStream_t st);
 void launch_derived(const Dev &P, hipStream_t st);

@@ -646,6 +646,230 @@ template <bool ROWU> __global__ void k_visc_fused(const Dev P)
     }
 }
 
+
+// ===========================================================================
+// Wave-marching source step (isothermal EOS): the whole chain
+//   S1+S2 -> artificial viscosity -> stress tensor -> viscous update
+// in ONE pass over memory.  A wavefront owns 64 consecutive phi cells (phi neighbours by
+// wavefront shuffle) and marches outward ring by ring; every intermediate (v after the
+// source terms, Q_rr/Q_pp, v after artificial viscosity, div v, tau_*) lives in a rolling
+// register window of 2-4 rings, so each input ring (Sigma, Phi, v_r, v_phi) is read once
+// and each output ring (v_r, v_phi) written once: 6 doubles per cell.
+// Stage lags for the newest loaded ring m:
+//   A  v1(m)            source terms                      (SourceEuler.cpp:325-428)
+//   B  Q(m-1)           TW / SN artificial pressure        (artificial_viscosity.cpp:48-77,165-189)
+//   C  v2(m-1)          artificial-viscosity update        (artificial_viscosity.cpp:90-139,220-248)
+//   D  tau_diag(m-2), tau_rphi(m-1)                        (viscosity.cpp:149-254)
+//   E  v3(m-2) -> out   viscous update                     (viscosity.cpp:368-421)
+// Lane validity erodes by one cell per phi-coupled stage: lanes 3..61 of a segment are
+// final, segments advance by MARCH_VALID = 59 cells.  A chunk of MARCH_ROWS output rings
+// needs 5 extra input rings of warm-up.
+#define MARCH_VALID 59
+#define MARCH_LO 3
+
+template <int AV> // 0: none, 1: TW, 2: SN
+__global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int chunk = wave / segs;
+    const int seg = wave - chunk * segs;
+    const int nr = P.nr, nphi = P.nphi;
+    const int k0 = chunk * rows_per_chunk;
+    if (k0 > nr)
+        return;
+    const int k1 = (k0 + rows_per_chunk < nr + 1) ? k0 + rows_per_chunk : nr + 1; // v_r has rows 0..nr
+    const int jraw = seg * MARCH_VALID - MARCH_LO + lane;
+    const int j = jraw < 0 ? jraw + nphi : (jraw >= nphi ? jraw - nphi : jraw);
+    const bool store_lane = lane >= MARCH_LO && lane < MARCH_LO + MARCH_VALID && jraw < nphi;
+    const double dt = P.clk->dt;
+    const double OmF = P.omega_frame;
+    const double C2 = P.art_visc_factor * P.art_visc_factor;
+
+#define NEXT(x) __shfl_down((x), 1, 64) /* value of cell j+1 */
+#define PREV(x) __shfl_up((x), 1, 64)   /* value of cell j-1 */
+    auto crow = [nr](int r) { return r < 0 ? 0 : (r > nr - 1 ? nr - 1 : r); };   // cell rows
+    auto vrow = [nr](int r) { return r < 0 ? 0 : (r > nr ? nr : r); };           // v_r rows
+    auto nu_of = [&](int r) { return P.alpha_viscosity ? P.nu_ring[crow(r)] : P.nu_const; };
+
+    // rolling state (suffix _1.._3 = rings m-1..m-3)
+    double S_m = 0, S_1 = 0, S_2 = 0, S_3 = 0, Sp_m = 0, Sp_1 = 0, Sp_2 = 0; // Sigma and Sigma(j-1)
+    double F_m = 0, F_1 = 0;                                               // potential
+    double va0_m = 0, va0_1 = 0, va0n_m = 0, va0n_1 = 0;                   // v_phi (input) and (j+1)
+    double vr1_m = 0, vr1_1 = 0, va1_m = 0, va1_1 = 0;                      // after source terms
+    double qr_1 = 0, qr_2 = 0, qp_1 = 0, qp_2 = 0;                          // Q_rr/Q_pp (TW) or q_r/q_phi (SN)
+    double vr2_1 = 0, vr2_2 = 0, va2_1 = 0, va2_2 = 0;                      // after artificial viscosity
+    double trr_2 = 0, trr_3 = 0, tpp_2 = 0, tpp_3 = 0, trp_1 = 0, trp_2 = 0;
+
+    // ring k0-3 is the "previous" ring of the first iteration
+    {
+        const int r = crow(k0 - 3);
+        S_m = P.sigma[IDX(r, j)];
+        F_m = P.potential[IDX(r, j)];
+        va0_m = P.vazi[IDX(r, j)];
+        Sp_m = PREV(S_m);
+        va0n_m = NEXT(va0_m);
+    }
+    // software prefetch of the next input ring
+    int rn = k0 - 2;
+    double pS = P.sigma[IDX(crow(rn), j)], pF = P.potential[IDX(crow(rn), j)];
+    double pVa = P.vazi[IDX(crow(rn), j)], pVr = P.vrad[IDX(vrow(rn), j)];
+
+    for (int m = k0 - 2; m <= k1 + 1; ++m) {
+        // ---- shift the window, take the prefetched ring m, prefetch ring m+1 ------------
+        S_3 = S_2; S_2 = S_1; S_1 = S_m; Sp_2 = Sp_1; Sp_1 = Sp_m;
+        F_1 = F_m;
+        va0_1 = va0_m; va0n_1 = va0n_m;
+        vr1_1 = vr1_m; va1_1 = va1_m;
+        S_m = pS; F_m = pF; va0_m = pVa;
+        const double vr0_m = pVr;
+        {
+            const int r = m + 1;
+            pS = P.sigma[IDX(crow(r), j)];
+            pF = P.potential[IDX(crow(r), j)];
+            pVa = P.vazi[IDX(crow(r), j)];
+            pVr = P.vrad[IDX(vrow(r), j)];
+        }
+        Sp_m = PREV(S_m);
+        va0n_m = NEXT(va0_m);
+        const double Fp_m = PREV(F_m);
+
+        // ---- A: source terms on ring m ---------------------------------------------------
+        {
+            const int r = m;
+            const int rc = crow(r), rc1 = crow(r - 1);
+            const double cs_m = P.cs_ring[rc], cs_1 = P.cs_ring[rc1];
+            const double P_m = S_m * (cs_m * cs_m), P_1 = S_1 * (cs_1 * cs_1), Pp_m = Sp_m * (cs_m * cs_m);
+            vr1_m = vr0_m;
+            if (r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr) {
+                double gradp = 2.0 / (S_m + S_1);
+                gradp *= (P_m - P_1);
+                gradp *= P.InvDiffRmed[r];
+                const double gradphi = (F_m - F_1) * P.InvDiffRmed[r];
+                const double vsum = va0_m + va0n_m + va0_1 + va0n_1;
+                const double vt = 0.25 * vsum + P.Rinf[r] * OmF;
+                const double vt2 = vt * vt;
+                vr1_m = vr0_m + dt * (-gradp - gradphi + vt2 * P.InvRinf[r]);
+            }
+            va1_m = va0_m;
+            if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
+                const double invdxtheta = 2.0 / (P.dphi * (P.Rsup[r] + P.Rinf[r]));
+                const double gradp = 2.0 / (S_m + Sp_m) * (P_m - Pp_m) * invdxtheta;
+                const double gradphi = (F_m - Fp_m) * invdxtheta;
+                va1_m = va0_m + dt * (-gradp - gradphi);
+            }
+        }
+        // ---- B: artificial pressure on ring m-1 ------------------------------------------
+        qr_2 = qr_1; qp_2 = qp_1;
+        {
+            const int r = crow(m - 1);
+            const double va1n_1 = NEXT(va1_1);
+            if (AV == 1) {
+                const double eps_rr = (vr1_m - vr1_1) * P.InvDiffRsup[r];
+                const double eps_pp = P.InvRmed[r] * ((va1n_1 - va1_1) * P.invdphi + 0.5 * (vr1_m + vr1_1));
+                const double div_V = dmin(eps_rr + eps_pp, 0.0);
+                const double Dr = P.Rinf[r + 1] - P.Rinf[r];
+                const double rDphi = P.Rmed[r] * P.dphi;
+                const double dx = nphi <= 16 ? dmin(Dr, rDphi) : dmax(Dr, rDphi);
+                const double l_sq = C2 * (dx * dx);
+                qr_1 = l_sq * S_1 * -div_V * (eps_rr - 1.0 / 3.0 * div_V);
+                qp_1 = l_sq * S_1 * -div_V * (eps_pp - 1.0 / 3.0 * div_V);
+            } else if (AV == 2) {
+                const double dv_r = vr1_m - vr1_1;
+                qr_1 = dv_r < 0.0 ? C2 * S_1 * (dv_r * dv_r) : 0.0;
+                const double dv_phi = va1n_1 - va1_1;
+                qp_1 = dv_phi < 0.0 ? C2 * S_1 * (dv_phi * dv_phi) : 0.0;
+            }
+        }
+        // ---- C: artificial-viscosity update of ring m-1 -----------------------------------
+        vr2_2 = vr2_1; va2_2 = va2_1;
+        {
+            const int r = m - 1;
+            vr2_1 = vr1_1;
+            va2_1 = va1_1;
+            const bool upd_vr = r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr;
+            if (AV == 1) {
+                const double qpp_p = PREV(qp_1);
+                if (r >= 1 && r < nr - 1) {
+                    const double sigma_phi_avg = 0.5 * (S_1 + Sp_1);
+                    va2_1 = va1_1 + 2.0 * dt / ((P.Rsup[r] + P.Rinf[r]) * sigma_phi_avg) * (qp_1 - qpp_p) * P.invdphi;
+                }
+                if (upd_vr) {
+                    const double sigma_r_avg = 0.5 * (S_1 + S_2);
+                    const double rm = P.Rmed[r], rmm = P.Rmed[r - 1];
+                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt / sigma_r_avg * 2.0 / (rm * rm - rmm * rmm) *
+                                        ((qr_1 * rm - qr_2 * rmm) - 0.5 * (qp_1 + qp_2) * (rm - rmm));
+                }
+            } else if (AV == 2) {
+                const double qphi_p = PREV(qp_1);
+                if (upd_vr)
+                    vr2_1 = vr1_1 - dt * 2.0 / (S_1 + S_2) * (qr_1 - qr_2) * P.InvDiffRmed[r];
+                if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
+                    const double invdxtheta = 1.0 / (P.dphi * P.Rmed[r]);
+                    va2_1 = va1_1 - dt * 2.0 / (S_1 + Sp_1) * (qp_1 - qphi_p) * invdxtheta;
+                }
+            }
+        }
+        // ---- D: stress tensor: diagonal on ring m-2, r-phi on ring m-1 --------------------
+        trr_3 = trr_2; tpp_3 = tpp_2; trp_2 = trp_1;
+        {
+            const int r = crow(m - 2);
+            const double va2n_2 = NEXT(va2_2);
+            const double dva = va2n_2 - va2_2;
+            const double divv =
+                (vr2_1 * P.Rinf[r + 1] - vr2_2 * P.Rinf[r]) * P.InvDiffRsupRb[r] + dva * P.invdphi * P.InvRmed[r];
+            const double nu = nu_of(m - 2);
+            const double drr = (vr2_1 - vr2_2) * P.InvDiffRsup[r];
+            trr_2 = 2.0 * nu * S_2 * (drr - 1.0 / 3.0 * divv);
+            const double dpp = dva * P.invdphi * P.InvRmed[r] + 0.5 * (vr2_1 + vr2_2) * P.InvRmed[r];
+            tpp_2 = 2.0 * nu * S_2 * (dpp - 1.0 / 3.0 * divv);
+        }
+        {
+            const int r = m - 1;
+            const double vr2p_1 = PREV(vr2_1);
+            trp_1 = 0.0;
+            if (r >= 1 && r <= nr - 1) {
+                const double dvazirdr = (va2_1 * P.InvRmed[r] - va2_2 * P.InvRmed[r - 1]) * P.InvDiffRmed[r];
+                const double dvrdphi = (vr2_1 - vr2p_1) * P.invdphi;
+                const double drp = P.Rinf[r] * dvazirdr + dvrdphi * P.InvRinf[r];
+                const double nu1 = nu_of(r), nu2 = nu_of(r - 1);
+                const double nu = 0.25 * (nu1 + nu2 + nu1 + nu2);
+                const double sigma = 0.25 * (S_1 + S_2 + Sp_1 + Sp_2);
+                trp_1 = nu * sigma * drp;
+            }
+        }
+        // ---- E: viscous update of ring k = m-2 and store ----------------------------------
+        {
+            const int k = m - 2;
+            const double tpp_p = PREV(tpp_2);
+            const double trp_n = NEXT(trp_2);
+            if (k >= k0 && k < k1) {
+                double vr3 = vr2_2, va3 = va2_2;
+                if (k >= 1 && k < nr - 1) {
+                    const double sigma_avg = 0.5 * (S_2 + Sp_2);
+                    const double ra1 = P.Rinf[k + 1], ra0 = P.Rinf[k];
+                    va3 = va2_2 + dt * P.InvRmed[k] / (sigma_avg) *
+                                      ((2.0 / (ra1 * ra1 - ra0 * ra0)) * (ra1 * ra1 * trp_1 - ra0 * ra0 * trp_2) +
+                                       (tpp_2 - tpp_p) * P.invdphi);
+                }
+                if (k >= P.one_no_ghost_vr && k < P.maxmo_no_ghost_vr) {
+                    const double sigma_avg = 0.5 * (S_2 + S_3);
+                    vr3 = vr2_2 + dt / (sigma_avg)*P.radial_viscosity_factor * 2.0 / (P.Rmed[k] + P.Rmed[k - 1]) *
+                                      ((P.Rmed[k] * trr_2 - P.Rmed[k - 1] * trr_3) * P.InvDiffRmed[k] +
+                                       (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
+                }
+                if (store_lane) {
+                    P.vrad_b[IDX(k, j)] = vr3;
+                    if (k < nr)
+                        P.vazi_b[IDX(k, j)] = va3;
+                }
+            }
+        }
+    }
+#undef NEXT
+#undef PREV
+}
+
 // ---------------------------------------------------------------------------
 // boundary_conditions/{zero_gradient,reference,reflecting,outflow,keplerian_*,zero_shear}.cpp
 // called in the order of boundary_conditions.cpp:65-114; one thread per phi column.
@@ -1131,8 +1355,8 @@ __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, Thet
 
     int idx[C];
     double S[C], Q[4][C], E[C], V[C + 1];
-    const double mean = P.vmean[i];
-    const double vconst = P.vconst[i];
+    const double mean = P.vmean_c[i];
+    const double vconst = P.vconst_c[i];
     const double vadd = P.fast_transport ? 0.0 : vconst; // ComputeConstantResidual, non-FARGO branch
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -1278,7 +1502,7 @@ __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, Thet
 #undef THETA_STARS
 #undef THETA_EXT
     // AdvectSHIFT (:238-268): cell j lands in j + Nshift (Nshift folded into [0, nphi) once)
-    int nshift = P.nshift[i] % nphi;
+    int nshift = P.nshift_c[i] % nphi;
     nshift = nshift < 0 ? nshift + nphi : nshift;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -1542,6 +1766,24 @@ void launch_source_fused(const Dev &P, hipStream_t st)
 {
     LAUNCH2D(KID_SOURCE_VR, k_src_fused, P.nr + 1, P);
     LAUNCH2D(KID_TW_Q, k_av_fused, P.nr + 1, P);
+}
+// whole source step in one marching pass (isothermal, Nphi >= 128); returns false if not applicable
+bool launch_source_march(const Dev &P, hipStream_t st)
+{
+    if (P.adiabatic || P.nphi < 128)
+        return false;
+    const int rows = 32;
+    const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
+    const int chunks = (P.nr + 1 + rows - 1) / rows;
+    const int waves = segs * chunks;
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (P.art_visc == FCPT_ARTVISC_TW)
+        KLAUNCH(KID_SOURCE_VR, k_source_march<1>, grid, block, P, segs, rows);
+    else if (P.art_visc == FCPT_ARTVISC_SN)
+        KLAUNCH(KID_SOURCE_VR, k_source_march<2>, grid, block, P, segs, rows);
+    else
+        KLAUNCH(KID_SOURCE_VR, k_source_march<0>, grid, block, P, segs, rows);
+    return true;
 }
 void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_VR, k_visc_fused, P.nr + 1, P); }
 void launch_substep3_after_fused(const Dev &P, hipStream_t st)

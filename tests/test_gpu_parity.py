@@ -62,8 +62,22 @@ def test_shocktube_to_monitor_time(product, oracle):
 def test_two_slabs_match_one(product, oracle):
     """Radial split (split.cpp) + ghost exchange (commbound.cpp): 2 HIP slabs vs 1 oracle slab.
     The reference itself agrees to 4e-13 between 1 and 2 ranks."""
-    d = setups.planet_disk(product, 64, 96)
+    d = setups.planet_disk(product, 64, 192)
     _check(run_pair(product, oracle, d, 30, nslabs=(2, 1)), ("sigma", "vrad", "vazi"))
+    d = setups.planet_disk(product, 96, 64, adiabatic=True)
+    _check(run_pair(product, oracle, d, 20, nslabs=(3, 1)), ("sigma", "vrad", "vazi", "energy"))
+
+
+def test_marching_source_kernel_variants(product, oracle):
+    """The one-pass wave-marching source kernel (isothermal, Nphi >= 128) for SN and no
+    artificial viscosity, constant viscosity, and an odd ring count / Nphi not a multiple of 59."""
+    d = setups.planet_disk(product, 45, 250)
+    d.artificial_viscosity = B.ARTVISC_SN
+    _check(run_pair(product, oracle, d, 25, bodies=setups.jupiter_bodies(d)), ("sigma", "vrad", "vazi"))
+    d = setups.planet_disk(product, 40, 128)
+    d.artificial_viscosity = B.ARTVISC_NONE
+    d.viscous_alpha, d.constant_viscosity = 0.0, 1e-5
+    _check(run_pair(product, oracle, d, 25), ("sigma", "vrad", "vazi"))
 
 
 def test_tiled_azimuthal_sweep_32x640(product, oracle):
