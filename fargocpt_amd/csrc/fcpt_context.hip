@@ -38,6 +38,8 @@ struct fcpt_ctx {
     bool profiling = false;
     bool fused_source = true;
     bool march_source = true;
+    bool stepped = false; // fcpt_step ran since the last fcpt_post
+    bool pressure_valid = false;
 };
 
 namespace {
@@ -125,9 +127,9 @@ DampRange damp_range(const fcpt_ctx *c, int is_vector, int type, int outer)
 }
 
 // boundary_conditions.cpp:65-114
-void apply_boundary_view(fcpt_ctx *c, const Dev &P, bool final)
+void apply_boundary_view(fcpt_ctx *c, const Dev &P, bool final, bool damping_done = false)
 {
-    if (final && c->d.damping) {
+    if (final && c->d.damping && !damping_done) {
         // damping.cpp:754-774, order of damping_vector: vrad, vaz, sigma, energy
         for (int o = 0; o < 2; ++o)
             launch_damping(P, P.vrad, P.vrad0, P.Rinf.p, c->damp[0][o], 0, c->stream);
@@ -162,6 +164,16 @@ int read_clock(fcpt_ctx *c, DevClock *out)
     return FCPT_OK;
 }
 
+// isothermal pressure is Sigma c_s^2 with c_s fixed per ring: the marching source kernel forms
+// it in registers, so the grid is only materialised for callers that ask for it
+void ensure_pressure(fcpt_ctx *c)
+{
+    if (!c->pressure_valid) {
+        launch_pressure(c->P, c->stream);
+        c->pressure_valid = true;
+    }
+}
+
 // the gas part of step_Euler up to Transport (simulation.cpp:167-217)
 void enqueue_step(fcpt_ctx *c)
 {
@@ -173,6 +185,7 @@ void enqueue_step(fcpt_ctx *c)
     }
     if (c->fused_source) {
         if (!(c->march_source && launch_source_march(P, st))) { // one pass: (v) -> (v_b)
+            ensure_pressure(c);
             launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
             launch_recalculate_viscosity(P, st);
             launch_viscous_fused(P, st);         // (v) -> (v_b)
@@ -185,6 +198,7 @@ void enqueue_step(fcpt_ctx *c)
         apply_boundary_view(c, Q, false);
         launch_transport(Q, P, st);
     } else {
+        ensure_pressure(c);
         launch_source(P, st);
         launch_artificial_viscosity(P, st);
         launch_recalculate_viscosity(P, st);
@@ -196,12 +210,20 @@ void enqueue_step(fcpt_ctx *c)
         launch_transport(P, P, st);
     }
     launch_clock_advance(P.clk, st);
+    c->stepped = true;
 }
 
 void enqueue_post(fcpt_ctx *c)
 {
-    apply_boundary(c, true);
-    launch_derived(c->P, c->stream);
+    // the damping of the final boundary call was applied by k_velocities when damp_in_step
+    apply_boundary_view(c, c->P, true, c->P.damp_in_step != 0 && c->stepped);
+    c->stepped = false;
+    if (c->P.adiabatic) {
+        launch_derived(c->P, c->stream);
+        c->pressure_valid = true;
+    } else {
+        c->pressure_valid = false; // recalculate_derived_disk_quantities: P only, evaluated lazily
+    }
 }
 
 } // namespace
@@ -401,6 +423,56 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         for (int o = 0; o < 2; ++o)
             c->damp[q][o] = damp_range(c, q == 0, dtype[q][o], o);
 
+    {
+        // per-ring damping tables for the fused end-of-transport kernel (reference / zero targets;
+        // "mean" needs a ring reduction and keeps the separate k_damping launches)
+        std::vector<double> fs(nr + 1, 0.0), ts(nr + 1, 1.0), fv(nr + 1, 0.0), tv(nr + 1, 1.0);
+        std::vector<int> ty[4];
+        bool any = false, mean = false;
+        for (int q = 0; q < 4; ++q) {
+            ty[q].assign(nr + 1, 0);
+            for (int o = 0; o < 2; ++o) {
+                const DampRange &r = c->damp[q][o];
+                if (r.type == FCPT_DAMP_NONE || r.lo > r.hi)
+                    continue;
+                any = true;
+                mean = mean || r.type == FCPT_DAMP_MEAN;
+                const std::vector<double> &radius = q == 0 ? c->geo.Rinf : c->geo.Rmed;
+                for (int i = r.lo; i <= r.hi; ++i) {
+                    const double t = (radius[i] - r.rlim) / (r.redge - r.rlim);
+                    (q == 0 ? fv : fs)[i] = t * t;
+                    (q == 0 ? tv : ts)[i] = r.tau;
+                    ty[q][i] = r.type == FCPT_DAMP_REFERENCE ? 1 : 2;
+                }
+            }
+        }
+        auto upi = [&](CArrI &dst, const std::vector<int> &src) {
+            int *p = nullptr;
+            if (int e = dev_alloc(c, &p, src.size()))
+                return e;
+            if (hipMemcpy(p, src.data(), src.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+                return (int)FCPT_EHIP;
+            dst.p = p;
+            return (int)FCPT_OK;
+        };
+        if (!rc) rc = dev_upload(c, &P.dfac_s.p, fs);
+        if (!rc) rc = dev_upload(c, &P.dtau_s.p, ts);
+        if (!rc) rc = dev_upload(c, &P.dfac_v.p, fv);
+        if (!rc) rc = dev_upload(c, &P.dtau_v.p, tv);
+        if (!rc) rc = upi(P.dtype_vr, ty[0]);
+        if (!rc) rc = upi(P.dtype_va, ty[1]);
+        if (!rc) rc = upi(P.dtype_sig, ty[2]);
+        if (!rc) rc = upi(P.dtype_e, ty[3]);
+        if (rc) {
+            fcpt_destroy(c);
+            return rc;
+        }
+        P.damp_in_step = (d->damping && any && !mean) ? 1 : 0;
+        if (const char *e = getenv("FCPT_FUSED_DAMPING"))
+            if (e[0] == '0')
+                P.damp_in_step = 0;
+    }
+
     DevClock clk;
     std::memset(&clk, 0, sizeof(clk));
     clk.last_dt = d->first_dt; // Interpret.cpp:86
@@ -515,6 +587,8 @@ int fcpt_download(fcpt_ctx *c, int32_t f, double *host)
         set_error("bad argument to fcpt_download");
         return FCPT_EINVAL;
     }
+    if (f == FCPT_F_PRESSURE)
+        ensure_pressure(c);
     HIPCHK(hipMemcpyAsync(host, c->grid[f], grid_count(c, f) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return FCPT_OK;
@@ -581,6 +655,7 @@ int fcpt_init_physics(fcpt_ctx *c)
     if (int rc = copy_initial_values(c))
         return rc;
     c->potential_valid = false;
+    c->pressure_valid = true;
     HIPCHK(hipGetLastError());
     return FCPT_OK;
 }

@@ -98,6 +98,12 @@ struct Dev {
     double *vconst; // per ring constant residual velocity
     int *nshift;    // per ring integer shift
     CArr vmean_c, vconst_c; // the same arrays for kernels that only read them
+    // wave damping folded into the end of the transport step: per-ring factor f = ((r-r_lim)/(r_edge-r_lim))^2
+    // and time scale tau for scalar (dfac_s/dtau_s, nr) and vector (dfac_v/dtau_v, nr+1) grids, and the
+    // per-ring damping type of each field (0 none, 1 reference, 2 zero)
+    CArr dfac_s, dtau_s, dfac_v, dtau_v;
+    CArrI dtype_vr, dtype_va, dtype_sig, dtype_e;
+    int damp_in_step;
     CArrI nshift_c;
     double *cfl_part; // per-block maxima of the CFL reduction
     DevClock *clk;

@@ -1523,24 +1523,57 @@ __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, Thet
 
 // compute_velocities_from_momenta (:498-535) + assure_minimum_value and the
 // temperature floor/ceiling of Transport (:121-131); reads set B, writes the state.
-template <bool ROWU> __global__ void k_velocities(const Dev P, ThetaSet in, const double *vr_src)
+// Wave damping of one value (damping.cpp:311-557): X <- (X - X0) exp(-dt f / tau) + X0 on rings
+// whose per-ring type is non-zero (1: reference field, 2: zero / density floor).
+__device__ __forceinline__ double damp_value(const Dev &P, double X, int type, double fac, double tau,
+                                             double dt, const double *ref, int cell, double zero_target)
+{
+    if (type == 0)
+        return X;
+    const double exp_factor = exp(-dt * fac / tau);
+    const double X0 = type == 1 ? ref[cell] : zero_target;
+    return (X - X0) * exp_factor + X0;
+}
+// compute_velocities_from_momenta (:498-535) + assure_minimum_value and the temperature
+// floor/ceiling of Transport (:121-131); reads a momenta set, writes the state.  With
+// DAMP the reference/zero wave damping of the final boundary call (damping.cpp:754-774) is
+// applied to the fresh values in the same pass (the per-cell operations commute with the
+// ghost exchange that sits between them in the reference).
+template <bool DAMP, bool ROWU> __global__ void k_velocities(const Dev P, ThetaSet in, const double *vr_src)
 {
     CELL(0, P.nr);
-    if (i == P.nr - 1) // v_r row Nr is not transported: it keeps its post-boundary value
-        P.vrad[IDX(P.nr, j)] = vr_src[IDX(P.nr, j)];
+    const double dt = P.clk->dt;
+    if (i_ == P.nr - 1) { // v_r row Nr is not transported: it keeps its post-boundary value
+        double v = vr_src[IDX(P.nr, j)];
+        if (DAMP)
+            v = damp_value(P, v, P.dtype_vr[P.nr], P.dfac_v[P.nr], P.dtau_v[P.nr], dt, P.vrad0, IDX(P.nr, j), 0.0);
+        P.vrad[IDX(P.nr, j)] = v;
+    }
     const int jp = JPREV;
     const double s = in.sig[IDX(i, j)];
-    if (i == 0)
-        P.vrad[IDX(i, j)] = 0.0;
-    else
-        P.vrad[IDX(i, j)] = (in.rmp[IDX(i - 1, j)] + in.rmm[IDX(i, j)]) / (in.sig[IDX(i - 1, j)] + s);
-    P.vazi[IDX(i, j)] =
-        (in.lp[IDX(i, jp)] + in.lm[IDX(i, j)]) / (in.sig[IDX(i, jp)] + s) * P.InvRmed[i] -
-        P.Rmed[i] * P.omega_frame;
-    const double sf = s < P.sigma_floor_abs ? P.sigma_floor_abs : s;
+    double vr = 0.0;
+    if (i != 0)
+        vr = (in.rmp[IDX(i - 1, j)] + in.rmm[IDX(i, j)]) / (in.sig[IDX(i - 1, j)] + s);
+    double va = (in.lp[IDX(i, jp)] + in.lm[IDX(i, j)]) / (in.sig[IDX(i, jp)] + s) * P.InvRmed[i] -
+                P.Rmed[i] * P.omega_frame;
+    double sf = s < P.sigma_floor_abs ? P.sigma_floor_abs : s;
+    double e = 0.0;
+    if (P.adiabatic)
+        e = clamp_energy(P, in.e[IDX(i, j)], sf);
+    if (DAMP) {
+        const int c = IDX(i, j);
+        vr = damp_value(P, vr, P.dtype_vr[i], P.dfac_v[i], P.dtau_v[i], dt, P.vrad0, c, 0.0);
+        const double fs = P.dfac_s[i], ts = P.dtau_s[i];
+        va = damp_value(P, va, P.dtype_va[i], fs, ts, dt, P.vazi0, c, 0.0);
+        sf = damp_value(P, sf, P.dtype_sig[i], fs, ts, dt, P.sigma0, c, P.sigma_floor_abs);
+        if (P.adiabatic)
+            e = damp_value(P, e, P.dtype_e[i], fs, ts, dt, P.energy0, c, 0.0);
+    }
+    P.vrad[IDX(i, j)] = vr;
+    P.vazi[IDX(i, j)] = va;
     P.sigma[IDX(i, j)] = sf;
     if (P.adiabatic)
-        P.energy[IDX(i, j)] = clamp_energy(P, in.e[IDX(i, j)], sf);
+        P.energy[IDX(i, j)] = e;
 }
 
 // ---------------------------------------------------------------------------
@@ -1562,9 +1595,12 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
         const double inv_cell = dmax(inv_dxr, inv_dxa); // 1 / min(dxRadial, dxAzimuthal)
         const double lf = P.leapfrog ? 0.6 : 1.0;
         const double va = P.vazi[IDX(i, j)];
-        const double vres = P.fast_transport ? va - P.vmean[i] : va;
+        const double vres = P.fast_transport ? va - P.vmean_c[i] : va;
         const double vr0 = P.vrad[IDX(i, j)], vr1 = P.vrad[IDX(i + 1, j)];
-        const double invdt1 = P.soundspeed[IDX(i, j)] * inv_cell;
+        // isothermal: c_s and the alpha viscosity are per-ring constants (set once at init)
+        const double cs = P.adiabatic ? P.soundspeed[IDX(i, j)] : P.cs_ring[i];
+        const double nu = P.adiabatic ? P.viscosity[IDX(i, j)] : (P.alpha_viscosity ? P.nu_ring[i] : P.nu_const);
+        const double invdt1 = cs * inv_cell;
         const double invdt2 = vr0 * inv_dxr;
         const double invdt3 = vres * inv_dxa;
         const double C2 = P.art_visc_factor * P.art_visc_factor;
@@ -1582,7 +1618,7 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
             const double mdiv_V = -dmin(eps_rr + eps_pp, 0.0);
             invdt4 = 4.0 * C2 * mdiv_V * lf;
         }
-        const double invdt5 = 4.0 * P.viscosity[IDX(i, j)] * (inv_cell * inv_cell) * lf;
+        const double invdt5 = 4.0 * nu * (inv_cell * inv_cell) * lf;
         double invdt6 = 0.0;
         if (P.adiabatic) {
             const double inv_limit = 1.0 / P.heating_cooling_cfl_limit;
@@ -1881,11 +1917,17 @@ void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
             FUSED(6)
         }
 #undef FUSED
-        LAUNCH2D(KID_VELOCITIES, k_velocities, P.nr, W, inA, (const double *)P.vrad);
+        if (W.damp_in_step)
+            LAUNCH2D_T(KID_VELOCITIES, k_velocities, true, P.nr, W, inA, (const double *)P.vrad);
+        else
+            LAUNCH2D_T(KID_VELOCITIES, k_velocities, false, P.nr, W, inA, (const double *)P.vrad);
     } else {
         LAUNCH2D_T(KID_THETA1, k_transport_theta, 1, P.nr, P, inB, outA);
         LAUNCH2D_T(KID_THETA2, k_transport_theta, 2, P.nr, P, inA, outB);
-        LAUNCH2D(KID_VELOCITIES, k_velocities, P.nr, W, inB, (const double *)P.vrad);
+        if (W.damp_in_step)
+            LAUNCH2D_T(KID_VELOCITIES, k_velocities, true, P.nr, W, inB, (const double *)P.vrad);
+        else
+            LAUNCH2D_T(KID_VELOCITIES, k_velocities, false, P.nr, W, inB, (const double *)P.vrad);
     }
 }
 
