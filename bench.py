@@ -76,7 +76,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FCPT_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL group: rehearsal
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     lib = fargocpt_amd.load()
@@ -97,48 +98,30 @@ def main():
     adi = 1 if d.eos == B.EOS_IDEAL else 0
 
     # ---- one step ------------------------------------------------------------
-    if world == 1:
+    if not use_dist:
         def run(n):
             ctx.run_steps(n, snap=False)  # dt stays on the device, no host sync inside
-    else:
-        cnt = ctx.exchange_count()
-        s_in, s_out, r_in, r_out = (torch.empty(cnt, dtype=torch.float64, device=dev) for _ in range(4))
-        dt_t = torch.empty(1, dtype=torch.float64, device=dev)
-        has_in, has_out = rank > 0, rank < world - 1
 
-        def exchange():
-            ctx.exchange_pack(s_in.data_ptr() if has_in else None, s_out.data_ptr() if has_out else None)
-            ops = []
-            if has_in:
-                ops += [dist.P2POp(dist.isend, s_in, rank - 1), dist.P2POp(dist.irecv, r_in, rank - 1)]
-            if has_out:
-                ops += [dist.P2POp(dist.isend, s_out, rank + 1), dist.P2POp(dist.irecv, r_out, rank + 1)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            ctx.exchange_unpack(r_in.data_ptr() if has_in else None, r_out.data_ptr() if has_out else None)
+        def pre_loop():
+            for _ in range(2):
+                ctx.calculate_timestep(ctx.cfl())
+    else:
+        from fargocpt_amd.parallel import DistributedSlab
+        slab = DistributedSlab(ctx, device=dev)
 
         def run(n):
             for _ in range(n):
-                dt_t[0] = ctx.cfl()
-                dist.all_reduce(dt_t, op=dist.ReduceOp.MIN)  # cfl.cpp:379
-                dt = ctx.calculate_timestep(float(dt_t.item()))
-                ctx.step(dt)
-                exchange()  # commbound.cpp:98-182
-                ctx.post(dt)
+                slab.step_async()  # CFL -> all_reduce(MIN) -> policy -> step -> 7-ring exchange -> post
+
+        def pre_loop():
+            slab.prepare()
 
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
 
     # sim::init's pre-loop time-step calls (main.cpp:117, simulation.cpp:466-468)
-    if world == 1:
-        for _ in range(2):
-            ctx.calculate_timestep(ctx.cfl())
-    else:
-        for _ in range(2):
-            dt_t[0] = ctx.cfl()
-            dist.all_reduce(dt_t, op=dist.ReduceOp.MIN)
-            ctx.calculate_timestep(float(dt_t.item()))
+    pre_loop()
 
     # ---- warm-up, with a per-kernel calibration pass to find the dominant kernel --
     cal = min(3, max(1, args.warmup))
@@ -152,18 +135,18 @@ def main():
 
     # ---- timed region ---------------------------------------------------------
     ctx.profile_start([names.index(dominant)], max_launches=args.steps + 8)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     run(args.steps)
     sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
     dom = ctx.profile_stop()[dominant]
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -210,7 +193,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

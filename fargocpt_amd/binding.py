@@ -226,6 +226,19 @@ class Context:
         self._call("cfl", C.byref(v))
         return v.value
 
+    # device-resident dt (no host synchronisation); arguments are device addresses
+    def cfl_device(self, d_dt_local: int):
+        self._call("cfl_device", C.c_void_p(int(d_dt_local)))
+
+    def calculate_timestep_device(self, d_cfl_global: int):
+        self._call("calculate_timestep_device", C.c_void_p(int(d_cfl_global)))
+
+    def step_device(self):
+        self._call("step_device")
+
+    def post_device(self):
+        self._call("post_device")
+
     def calculate_timestep(self, cfl_dt_global: float) -> float:
         v = _f64()
         self._call("calculate_timestep", _f64(cfl_dt_global), C.byref(v))

@@ -676,6 +676,47 @@ int fcpt_cfl(fcpt_ctx *c, double *dt_local)
     return FCPT_OK;
 }
 
+int fcpt_cfl_device(fcpt_ctx *c, double *d_dt_local)
+{
+    if (!c || !d_dt_local)
+        return FCPT_EINVAL;
+    ProfScope prof_scope(c);
+    launch_cfl(c->P, c->stream);
+    launch_clock_export_cfl(c->P.clk, d_dt_local, c->stream);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_calculate_timestep_device(fcpt_ctx *c, const double *d_cfl_global)
+{
+    if (!c || !d_cfl_global)
+        return FCPT_EINVAL;
+    ProfScope prof_scope(c);
+    launch_clock_policy_ptr(c->P.clk, c->d.cfl_max_var, d_cfl_global, c->stream);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_step_device(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    ProfScope prof_scope(c);
+    enqueue_step(c);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_post_device(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    ProfScope prof_scope(c);
+    enqueue_post(c);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
 int fcpt_calculate_timestep(fcpt_ctx *c, double cfl_dt_global, double *dt)
 {
     if (!c || !dt)

@@ -52,6 +52,8 @@ void launch_pressure(const Dev &P, hipStream_t st);
 void launch_temperature(const Dev &P, hipStream_t st);
 void launch_cfl(const Dev &P, hipStream_t st);
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st);
+void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st);
+void launch_clock_policy_ptr(DevClock *clk, double cfl_max_var, const double *cfl_global, hipStream_t st);
 void launch_clock_advance(DevClock *clk, hipStream_t st);
 void launch_clock_policy(DevClock *clk, double cfl_max_var, int use_device_cfl, double cfl_global,
                          hipStream_t st);

@@ -1680,6 +1680,19 @@ __global__ void k_clock_advance(DevClock *clk)
     clk->time += clk->dt;
     clk->n_hydro_iter += 1;
 }
+__global__ void k_clock_export_cfl(const DevClock *clk, double *out)
+{
+    *out = __longlong_as_double((long long)clk->cfl_bits);
+}
+__global__ void k_clock_policy_ptr(DevClock *clk, double cfl_max_var, const double *cfl_global)
+{
+    const double cfl_dt = *cfl_global;
+    const double a = cfl_max_var * clk->last_dt;
+    const double rv = cfl_dt < a ? cfl_dt : a;
+    clk->cfl_dt = rv;
+    clk->last_dt = rv;
+    clk->dt = rv;
+}
 // sim::CalculateTimeStep (simulation.cpp:100-118): rv = min(CFLmaxVar*last_dt, cfl_dt)
 __global__ void k_clock_policy(DevClock *clk, double cfl_max_var, int use_device_cfl, double cfl_global)
 {
@@ -1964,6 +1977,14 @@ void launch_cfl(const Dev &P, hipStream_t st)
     KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, nparts);
 }
 
+void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st)
+{
+    KLAUNCH(KID_CLOCK, k_clock_export_cfl, dim3(1), dim3(1), (const DevClock *)clk, out);
+}
+void launch_clock_policy_ptr(DevClock *clk, double cfl_max_var, const double *cfl_global, hipStream_t st)
+{
+    KLAUNCH(KID_CLOCK, k_clock_policy_ptr, dim3(1), dim3(1), clk, cfl_max_var, cfl_global);
+}
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st)
 {
     KLAUNCH(KID_CLOCK, k_clock_set_dt, dim3(1), dim3(1), clk, dt);

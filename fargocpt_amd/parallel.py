@@ -21,8 +21,9 @@ from . import binding as B
 class DistributedSlab:
     def __init__(self, ctx: B.Context, device: torch.device | None = None):
         self.ctx = ctx
-        self.rank = dist.get_rank()
-        self.world = dist.get_world_size()
+        ready = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if ready else 0
+        self.world = dist.get_world_size() if ready else 1
         self.device = device or torch.device("cpu")
         self.on_gpu = self.device.type == "cuda"
         cnt = ctx.exchange_count()
@@ -62,6 +63,19 @@ class DistributedSlab:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         self.ctx.exchange_unpack(self._arg(self.r_in), self._arg(self.r_out))
+
+    def step_async(self):
+        """One step with dt kept on the device (GPU slabs only): CFL kernels, MIN all-reduce of a
+        one-element device tensor, policy kernel, step, exchange, post -- all enqueued on the
+        current stream, no host synchronisation."""
+        assert self.on_gpu
+        self.ctx.cfl_device(self._dt.data_ptr())
+        if self.world > 1:
+            dist.all_reduce(self._dt, op=dist.ReduceOp.MIN)
+        self.ctx.calculate_timestep_device(self._dt.data_ptr())
+        self.ctx.step_device()
+        self.exchange()
+        self.ctx.post_device()
 
     def prepare(self):
         """main.cpp:117,147 and sim::init (simulation.cpp:462-474)."""

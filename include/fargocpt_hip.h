@@ -282,6 +282,17 @@ int fcpt_init_physics(fcpt_ctx *ctx);
  * minimum over this slab's active rings.  Blocks until the value is on the host. */
 int fcpt_cfl(fcpt_ctx *ctx, double *dt_local);
 
+/* Device-resident variants for multi-slab runs that keep dt off the host: fcpt_cfl_device
+ * writes this slab's CFL minimum to *d_dt_local (a device address, e.g. of a tensor the
+ * caller then MIN-all-reduces with RCCL on the same stream); fcpt_calculate_timestep_device
+ * applies the CalculateTimeStep policy to the reduced value read from *d_cfl_global and
+ * leaves the step length in the device clock, where fcpt_step_device / fcpt_post_device
+ * pick it up.  No call in this group synchronises with the host. */
+int fcpt_cfl_device(fcpt_ctx *ctx, double *d_dt_local);
+int fcpt_calculate_timestep_device(fcpt_ctx *ctx, const double *d_cfl_global);
+int fcpt_step_device(fcpt_ctx *ctx);
+int fcpt_post_device(fcpt_ctx *ctx);
+
 /* sim::CalculateTimeStep's policy (src/simulation.cpp:100-118) applied to the
  * globally reduced CFL dt: returns min(CFLmaxVar*last_dt, cfl_dt) and stores it
  * as last_dt. */

@@ -102,3 +102,35 @@ def test_mc_limiter_and_standard_transport(product, oracle):
     d.flux_limiter = B.LIMITER_MC
     d.fast_transport = 0
     _check(run_pair(product, oracle, d, 20), ("sigma", "vrad", "vazi"))
+
+
+def test_device_resident_dt_loop(product):
+    """fcpt_run_steps (snap=0) and the DistributedSlab.step_async loop keep dt on the device;
+    both must reproduce the host-driven loop (cfl -> calculate_timestep -> step -> post) exactly."""
+    import torch
+    from fargocpt_amd import driver
+    from fargocpt_amd.parallel import DistributedSlab
+    d = setups.planet_disk(product, 64, 256)
+    radii = product.radii(d)
+    fields = product.initial_fields(d.copy(), radii)
+    states = []
+    for mode in ("host", "run_steps", "async"):
+        ctx = driver.make_context(product, d, fields=fields, radii=radii, bodies=setups.jupiter_bodies(d))
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        if mode == "host":
+            S.run(12)
+        elif mode == "run_steps":
+            assert ctx.run_steps(12) == 12
+        else:
+            slab = DistributedSlab(ctx, device=torch.device("cuda", 0))
+            for _ in range(12):
+                slab.step_async()
+        st = ctx.state()
+        st["time"] = ctx.clock.time
+        states.append(st)
+        ctx.close()
+    for other in states[1:]:
+        assert other["time"] == states[0]["time"]
+        for k in ("sigma", "vrad", "vazi"):
+            assert np.array_equal(other[k], states[0][k]), k
