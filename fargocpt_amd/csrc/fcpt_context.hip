@@ -307,6 +307,24 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     c->d_cs_ring = const_cast<double *>(csr);
     P.cs_ring.p = csr;
     {
+        const HostGeometry &g = c->geo;
+        std::vector<double> a(nr + 1, 0.0), b(nr + 1, 0.0), c2(nr + 1, 0.0), d2(nr + 1, 0.0), e2(nr + 1, 0.0);
+        for (int i = 0; i <= nr; ++i) {
+            a[i] = 2.0 / (g.dphi * (g.Rsup[i] + g.Rinf[i]));
+            b[i] = 1.0 / (g.Rsup[i] + g.Rinf[i]);
+            d2[i] = 1.0 / (g.Rinf[i + 1] * g.Rinf[i + 1] - g.Rinf[i] * g.Rinf[i]);
+            if (i >= 1) {
+                c2[i] = 1.0 / (g.Rmed[i] * g.Rmed[i] - g.Rmed[i - 1] * g.Rmed[i - 1]);
+                e2[i] = 1.0 / (g.Rmed[i] + g.Rmed[i - 1]);
+            }
+        }
+        if (!rc) rc = dev_upload(c, &P.g_inv_dxt_src.p, a);
+        if (!rc) rc = dev_upload(c, &P.g_inv_rsum.p, b);
+        if (!rc) rc = dev_upload(c, &P.g_inv_drmed2.p, c2);
+        if (!rc) rc = dev_upload(c, &P.g_inv_dra2.p, d2);
+        if (!rc) rc = dev_upload(c, &P.g_inv_rmsum.p, e2);
+    }
+    {
         // isothermal alpha viscosity per ring, exactly as k_iso_cs_h + k_viscosity evaluate it:
         // H = cs * (1 / Omega_K), nu = alpha * H * cs
         std::vector<double> nu_ring(nr);

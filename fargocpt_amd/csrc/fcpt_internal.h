@@ -82,6 +82,10 @@ struct Dev {
     CArr Rmed, Rinf, Rsup, Surf, InvRmed, InvRinf, InvSurf, InvDiffRmed, InvDiffRsup, InvDiffRsupRb;
     const double *cosphi, *sinphi; // cos/sin(dphi * j), j < nphi (SideEuler.cpp:60-63)
     CArr cs_ring, nu_ring; // isothermal sound speed and alpha-viscosity per ring
+    // per-ring reciprocals used by the marching source kernel (host-evaluated, IEEE):
+    //   g_inv_dxt_src = 2/(dphi (Rsup+Rinf)), g_inv_rsum = 1/(Rsup+Rinf), g_inv_drmed2 = 1/(Rmed[i]^2-Rmed[i-1]^2),
+    //   g_inv_dra2 = 1/(Rinf[i+1]^2-Rinf[i]^2), g_inv_rmsum = 1/(Rmed[i]+Rmed[i-1])
+    CArr g_inv_dxt_src, g_inv_rsum, g_inv_drmed2, g_inv_dra2, g_inv_rmsum;
     // state
     double *sigma, *vrad, *vazi, *energy;
     double *vrad_b, *vazi_b; // intermediate velocities of the fused source step

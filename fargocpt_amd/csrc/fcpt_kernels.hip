@@ -58,6 +58,14 @@ __device__ __forceinline__ double fast_rcp(double d)
     return x;
 }
 
+// One Newton step: relative error <= 2e-15 (measured on MI355X, profiles/tools/rcp_accuracy.hip);
+// used for the van Leer slope, whose error enters the state scaled by (dx - v dt) dq / Q << 1.
+__device__ __forceinline__ double fast_rcp1(double d)
+{
+    const double x = __builtin_amdgcn_rcp(d);
+    return fma(x, fma(-d, x, 1.0), x);
+}
+
 __device__ __forceinline__ double dmin(double a, double b) { return b < a ? b : a; } // std::min
 __device__ __forceinline__ double dmax(double a, double b) { return a < b ? b : a; } // std::max
 
@@ -742,7 +750,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
             const double P_m = S_m * (cs_m * cs_m), P_1 = S_1 * (cs_1 * cs_1), Pp_m = Sp_m * (cs_m * cs_m);
             vr1_m = vr0_m;
             if (r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr) {
-                double gradp = 2.0 / (S_m + S_1);
+                double gradp = 2.0 * fast_rcp(S_m + S_1);
                 gradp *= (P_m - P_1);
                 gradp *= P.InvDiffRmed[r];
                 const double gradphi = (F_m - F_1) * P.InvDiffRmed[r];
@@ -753,8 +761,8 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
             }
             va1_m = va0_m;
             if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
-                const double invdxtheta = 2.0 / (P.dphi * (P.Rsup[r] + P.Rinf[r]));
-                const double gradp = 2.0 / (S_m + Sp_m) * (P_m - Pp_m) * invdxtheta;
+                const double invdxtheta = P.g_inv_dxt_src[r]; // 2 / (dphi (Rsup + Rinf))
+                const double gradp = 2.0 * fast_rcp(S_m + Sp_m) * (P_m - Pp_m) * invdxtheta;
                 const double gradphi = (F_m - Fp_m) * invdxtheta;
                 va1_m = va0_m + dt * (-gradp - gradphi);
             }
@@ -792,21 +800,21 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                 const double qpp_p = PREV(qp_1);
                 if (r >= 1 && r < nr - 1) {
                     const double sigma_phi_avg = 0.5 * (S_1 + Sp_1);
-                    va2_1 = va1_1 + 2.0 * dt / ((P.Rsup[r] + P.Rinf[r]) * sigma_phi_avg) * (qp_1 - qpp_p) * P.invdphi;
+                    va2_1 = va1_1 + 2.0 * dt * (P.g_inv_rsum[r] * fast_rcp(sigma_phi_avg)) * (qp_1 - qpp_p) * P.invdphi;
                 }
                 if (upd_vr) {
                     const double sigma_r_avg = 0.5 * (S_1 + S_2);
                     const double rm = P.Rmed[r], rmm = P.Rmed[r - 1];
-                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt / sigma_r_avg * 2.0 / (rm * rm - rmm * rmm) *
+                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt * fast_rcp(sigma_r_avg) * 2.0 * P.g_inv_drmed2[r] *
                                         ((qr_1 * rm - qr_2 * rmm) - 0.5 * (qp_1 + qp_2) * (rm - rmm));
                 }
             } else if (AV == 2) {
                 const double qphi_p = PREV(qp_1);
                 if (upd_vr)
-                    vr2_1 = vr1_1 - dt * 2.0 / (S_1 + S_2) * (qr_1 - qr_2) * P.InvDiffRmed[r];
+                    vr2_1 = vr1_1 - dt * 2.0 * fast_rcp(S_1 + S_2) * (qr_1 - qr_2) * P.InvDiffRmed[r];
                 if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
-                    const double invdxtheta = 1.0 / (P.dphi * P.Rmed[r]);
-                    va2_1 = va1_1 - dt * 2.0 / (S_1 + Sp_1) * (qp_1 - qphi_p) * invdxtheta;
+                    const double invdxtheta = P.InvRmed[r] * P.invdphi;
+                    va2_1 = va1_1 - dt * 2.0 * fast_rcp(S_1 + Sp_1) * (qp_1 - qphi_p) * invdxtheta;
                 }
             }
         }
@@ -848,13 +856,13 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                 if (k >= 1 && k < nr - 1) {
                     const double sigma_avg = 0.5 * (S_2 + Sp_2);
                     const double ra1 = P.Rinf[k + 1], ra0 = P.Rinf[k];
-                    va3 = va2_2 + dt * P.InvRmed[k] / (sigma_avg) *
-                                      ((2.0 / (ra1 * ra1 - ra0 * ra0)) * (ra1 * ra1 * trp_1 - ra0 * ra0 * trp_2) +
+                    va3 = va2_2 + dt * P.InvRmed[k] * fast_rcp(sigma_avg) *
+                                      ((2.0 * P.g_inv_dra2[k]) * (ra1 * ra1 * trp_1 - ra0 * ra0 * trp_2) +
                                        (tpp_2 - tpp_p) * P.invdphi);
                 }
                 if (k >= P.one_no_ghost_vr && k < P.maxmo_no_ghost_vr) {
                     const double sigma_avg = 0.5 * (S_2 + S_3);
-                    vr3 = vr2_2 + dt / (sigma_avg)*P.radial_viscosity_factor * 2.0 / (P.Rmed[k] + P.Rmed[k - 1]) *
+                    vr3 = vr2_2 + dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * P.g_inv_rmsum[k] *
                                       ((P.Rmed[k] * trr_2 - P.Rmed[k - 1] * trr_3) * P.InvDiffRmed[k] +
                                        (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
                 }
@@ -1028,7 +1036,7 @@ __device__ __forceinline__ double limiter(int type, double a, double b)
         return 0.0;
     }
     const double ab = a * b;
-    return ab > 0.0 ? 2.0 * ab * fast_rcp(a + b) : 0.0;
+    return ab > 0.0 ? 2.0 * ab * fast_rcp1(a + b) : 0.0;
 }
 
 // Upwind "star" state at radial interface k (between rings k-1 and k),
@@ -1905,8 +1913,11 @@ void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
             C = c;
             periodic = 1;
         }
-    if (!C && P.nphi > 64 * 4)
-        C = 4;
+    if (!C && P.nphi > 64 * 2)
+        C = 2; // measured on MI355X at Nphi = 4096: C = 2 / 4 / 6 -> 0.195 / 0.280 / 0.358 ms (occupancy wins)
+    if (const char *e = getenv("FCPT_THETA_C")) // tuning knob: cells per lane in tiled mode
+        if (!periodic && (e[0] == '2' || e[0] == '4' || e[0] == '6') && P.nphi > 64 * (e[0] - '0'))
+            C = e[0] - '0';
     if (const char *e = getenv("FCPT_THETA_FUSED")) {
         if (e[0] == '0')
             C = 0;
