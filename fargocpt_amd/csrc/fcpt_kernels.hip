@@ -1378,23 +1378,19 @@ __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, Thet
         E[c] = ADI ? in.e[g] : 0.0;
         V[c] = vadd + (P.vazi[g] - mean);
     }
-    // input halo of the segment ends (tiled mode): two cells left of lane 0, two right of lane 63
-    double hS[2] = {1.0, 1.0}, hW[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}}, hV = 0.0;
+    // input halo of the segment ends (tiled mode): two cells left of lane 0, two right of lane 63.
+    // Only Sigma, 1/Sigma and the velocity are kept; the quantities are re-read when used (two
+    // lanes per wavefront), which keeps the kernel under 128 VGPRs (4 wavefronts per SIMD).
+    double hS[2] = {1.0, 1.0}, hR[2] = {1.0, 1.0}, hV = 0.0;
+    int hG[2] = {row, row};
     if (edge_l || edge_r) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int g = row + wrap(edge_l ? a - 2 + h : a + 64 * C + h);
-            const double s = in.sig[g];
-            const double rs = fast_rcp(s);
-            hS[h] = s;
-            hW[0][h] = in.rmp[g] * rs;
-            hW[1][h] = in.rmm[g] * rs;
-            hW[2][h] = in.lp[g] * rs;
-            hW[3][h] = in.lm[g] * rs;
-            hW[4][h] = ADI ? in.e[g] * rs : 0.0;
-            if (h == 0)
-                hV = vadd + (P.vazi[g] - mean);
+            hG[h] = row + wrap(edge_l ? a - 2 + h : a + 64 * C + h);
+            hS[h] = in.sig[hG[h]];
+            hR[h] = fast_rcp(hS[h]);
         }
+        hV = vadd + (P.vazi[hG[0]] - mean);
     }
     const double dxtheta = P.dphi * P.Rmed[i];
     const double invdxtheta = 1.0 / dxtheta;
@@ -1467,11 +1463,16 @@ __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, Thet
 #pragma unroll
         for (int c = 0; c < C; ++c)
             rS[c] = fast_rcp(S[c]);
-#define THETA_Q(X, HW)                                                                               \
+#define THETA_Q(X, INP)                                                                              \
         {                                                                                            \
             double W[C], we[C + 4], qs[C + 1], fl[C + 1];                                            \
             _Pragma("unroll") for (int c = 0; c < C; ++c) W[c] = X[c] * rS[c];                       \
-            THETA_EXT(we, W, HW[0], HW[1], first);                                                   \
+            double e0 = 0.0, e1 = 0.0;                                                               \
+            if (first && (edge_l || edge_r)) {                                                       \
+                e0 = INP[hG[0]] * hR[0];                                                             \
+                e1 = INP[hG[1]] * hR[1];                                                             \
+            }                                                                                        \
+            THETA_EXT(we, W, e0, e1, first);                                                         \
             if (first) {                                                                             \
                 THETA_STARS(qs, we, false, false);                                                   \
             } else if (uni_up) {                                                                     \
@@ -1487,12 +1488,12 @@ __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, Thet
                 X[c] += varq * invsurf;                                                              \
             }                                                                                        \
         }
-        THETA_Q(Q[0], hW[0]);
-        THETA_Q(Q[1], hW[1]);
-        THETA_Q(Q[2], hW[2]);
-        THETA_Q(Q[3], hW[3]);
+        THETA_Q(Q[0], in.rmp);
+        THETA_Q(Q[1], in.rmm);
+        THETA_Q(Q[2], in.lp);
+        THETA_Q(Q[3], in.lm);
         if (ADI)
-            THETA_Q(E, hW[4]);
+            THETA_Q(E, in.e);
         {
             double fl[C + 1];
 #pragma unroll
