@@ -1323,14 +1323,17 @@ template <int PASS, bool ROWU> __global__ void k_transport_theta(const Dev P, Th
 // ---------------------------------------------------------------------------
 // OneWindTheta (:270-288) in ONE kernel: residual pass, uniform pass and the integer
 // shift.  A wavefront owns a segment of one ring; every lane keeps C contiguous cells of
-// all transported quantities in registers, neighbours' edge cells arrive by wavefront
-// shuffles (no LDS, no barriers), star states are evaluated once per interface.
+// all transported quantities in registers.  Nothing is computed twice: a lane evaluates the
+// limited slope of its own cells and the star state / flux at the lower face of its own
+// cells; the left neighbour's edge value and slope and the right neighbour's first flux
+// arrive by wavefront shuffle (no LDS, no barriers).
 //   * "periodic" mode (Nphi <= 64 C, Nphi % C == 0): one wavefront holds the whole ring and
 //     the shuffles wrap around.
-//   * tiled mode: segments of 64 C cells advance by 64 C - 4; the residual pass is valid on
-//     the whole segment (its two-cell input halo is loaded), the uniform pass on all but two
-//     cells at each end, which the neighbouring segment owns.
+//   * tiled mode: each pass invalidates two cells at either end of a segment (their stencil
+//     leaves the segment), so segments of 64 C cells advance by 64 C - 8 and only the inner
+//     cells are stored.
 // Reads set B (+ v_phi, <v_phi>, Nshift), writes set A: 11 (13) doubles per cell.
+#define THETA_HALO 4
 template <int C, bool ADI>
 __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, ThetaSet in, ThetaOut out,
                                                               int tiles, int periodic)
@@ -1342,33 +1345,32 @@ __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, Thet
         return;
     const int tile = wave - i * tiles;
     const int nphi = P.nphi;
-    const int nl = periodic == 1 ? nphi / C : 64;          // lanes that own cells
-    const int stride = periodic == 1 ? nphi : 64 * C - 4;
-    const int a = periodic == 1 ? 0 : tile * stride - 2;   // first cell of the segment, in [-2, nphi)
+    const int nl = periodic ? nphi / C : 64;                    // lanes that own cells
+    const int stride = periodic ? nphi : 64 * C - 2 * THETA_HALO;
+    const int a = periodic ? 0 : tile * stride - THETA_HALO;    // first cell of the segment
     const bool act = lane < nl;
     const int ln = act ? lane : 0;
     int lsrc_l = ln - 1, lsrc_r = ln + 1;
-    if (periodic == 1) {
+    if (periodic) {
         lsrc_l = lsrc_l < 0 ? nl - 1 : lsrc_l;
         lsrc_r = lsrc_r >= nl ? 0 : lsrc_r;
     } else {
         lsrc_l = lsrc_l < 0 ? 0 : lsrc_l;
         lsrc_r = lsrc_r > 63 ? 63 : lsrc_r;
     }
-    const bool edge_l = periodic != 1 && lane == 0, edge_r = periodic != 1 && lane == 63;
     const double dt = P.clk->dt;
     const int row = i * nphi;
-    // all cell indices of a segment lie in [-4, 2 nphi): one conditional fold replaces '%'
+    // all cell indices of a segment lie in (-nphi, 2 nphi): one conditional fold replaces '%'
     auto wrap = [nphi](int j) { return j < 0 ? j + nphi : (j >= nphi ? j - nphi : j); };
 
     int idx[C];
-    double S[C], Q[4][C], E[C], V[C + 1];
+    double S[C], Q[4][C], E[C], V[C];
     const double mean = P.vmean_c[i];
     const double vconst = P.vconst_c[i];
     const double vadd = P.fast_transport ? 0.0 : vconst; // ComputeConstantResidual, non-FARGO branch
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        idx[c] = wrap(periodic == 2 ? a + c * 64 + ln : a + ln * C + c);
+        idx[c] = wrap(a + ln * C + c);
         const int g = row + idx[c];
         S[c] = in.sig[g];
         Q[0][c] = in.rmp[g];
@@ -1376,129 +1378,88 @@ __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, Thet
         Q[2][c] = in.lp[g];
         Q[3][c] = in.lm[g];
         E[c] = ADI ? in.e[g] : 0.0;
-        V[c] = vadd + (P.vazi[g] - mean);
-    }
-    // input halo of the segment ends (tiled mode): two cells left of lane 0, two right of lane 63.
-    // Only Sigma, 1/Sigma and the velocity are kept; the quantities are re-read when used (two
-    // lanes per wavefront), which keeps the kernel under 128 VGPRs (4 wavefronts per SIMD).
-    double hS[2] = {1.0, 1.0}, hR[2] = {1.0, 1.0}, hV = 0.0;
-    int hG[2] = {row, row};
-    if (edge_l || edge_r) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            hG[h] = row + wrap(edge_l ? a - 2 + h : a + 64 * C + h);
-            hS[h] = in.sig[hG[h]];
-            hR[h] = fast_rcp(hS[h]);
-        }
-        hV = vadd + (P.vazi[hG[0]] - mean);
+        V[c] = vadd + (P.vazi[g] - mean); // residual velocity at the lower face of cell c
     }
     const double dxtheta = P.dphi * P.Rmed[i];
     const double invdxtheta = 1.0 / dxtheta;
     const double dxrad = (P.Rsup[i] - P.Rinf[i]) * dt;
     const double invsurf = P.InvSurf[i];
 
-    // ext[0..C+3] = {left2, own C, right2} of an array whose own part is x[]
-#define THETA_EXT(ext, x, eh0, eh1, first_pass)                                   \
-    {                                                                             \
-        const double l0 = __shfl(x[C - 2], lsrc_l, 64), l1 = __shfl(x[C - 1], lsrc_l, 64); \
-        const double r0 = __shfl(x[0], lsrc_r, 64), r1 = __shfl(x[1], lsrc_r, 64); \
-        ext[0] = (edge_l) ? ((first_pass) ? eh0 : x[0]) : l0;                     \
-        ext[1] = (edge_l) ? ((first_pass) ? eh1 : x[1]) : l1;                     \
-        _Pragma("unroll") for (int c = 0; c < C; ++c) ext[2 + c] = x[c];          \
-        ext[C + 2] = (edge_r) ? ((first_pass) ? eh0 : x[C - 2]) : r0;             \
-        ext[C + 3] = (edge_r) ? ((first_pass) ? eh1 : x[C - 1]) : r1;             \
-    }
-    // ComputeStarTheta (:416-466) on an extended array: limited slope of cell m-1 in dq[m],
-    // then the upwind state at interfaces 0..C (interface k lies between ext[k+1] and ext[k+2]).
-    // UNI: the velocity is uniform along the ring (second pass), the upwind side is a scalar.
-#define THETA_STARS(st, ext, UNI, uni_up)                                                     \
-    {                                                                                         \
-        double dq[C + 2];                                                                     \
-        _Pragma("unroll") for (int m = 0; m < C + 2; ++m)                                     \
-        {                                                                                     \
-            if (!(UNI) || ((uni_up) ? (m <= C) : (m >= 1)))                                   \
-                dq[m] = 0.5 * limiter(P.limiter, ext[m + 2] - ext[m + 1], ext[m + 1] - ext[m]) * invdxtheta; \
-            else                                                                              \
-                dq[m] = 0.0;                                                                  \
-        }                                                                                     \
-        _Pragma("unroll") for (int k = 0; k <= C; ++k)                                        \
-        {                                                                                     \
-            const double xa = up[k] ? ext[k + 1] : ext[k + 2];                                \
-            const double sl = up[k] ? dq[k] : dq[k + 1];                                      \
-            st[k] = xa + dist[k] * sl;                                                        \
-        }                                                                                     \
+    // ComputeStarTheta (:416-466) + the flux of VanLeerTheta (:655-658) at the lower faces of
+    // the lane's cells for the array W[] (own cells); fac[c] = dxrad * rho*(c) * v(c) (or dxrad
+    // v(c) for the density itself).  fl[C] is the right neighbour's first flux.
+#define THETA_FLUX(fl, st, W, fac, HAVE_ST)                                                        \
+    {                                                                                               \
+        const double wl = __shfl(W[C - 1], lsrc_l, 64); /* cell -1 */                               \
+        const double wr = __shfl(W[0], lsrc_r, 64);     /* cell C  */                               \
+        double dq[C];                                                                               \
+        _Pragma("unroll") for (int c = 0; c < C; ++c)                                               \
+        {                                                                                           \
+            const double wm = c == 0 ? wl : W[c == 0 ? 0 : c - 1];                                 \
+            const double wp = c == C - 1 ? wr : W[c == C - 1 ? C - 1 : c + 1];                      \
+            dq[c] = 0.5 * limiter(P.limiter, wp - W[c], W[c] - wm) * invdxtheta;                    \
+        }                                                                                           \
+        const double dql = __shfl(dq[C - 1], lsrc_l, 64); /* slope of cell -1 */                    \
+        _Pragma("unroll") for (int c = 0; c < C; ++c)                                               \
+        {                                                                                           \
+            const double xa = up[c] ? (c == 0 ? wl : W[c == 0 ? 0 : c - 1]) : W[c];                 \
+            const double sl = up[c] ? (c == 0 ? dql : dq[c == 0 ? 0 : c - 1]) : dq[c];              \
+            const double star = xa + dist[c] * sl;                                                  \
+            if (HAVE_ST)                                                                            \
+                st[c] = star;                                                                       \
+            fl[c] = (HAVE_ST) ? 0.0 : fac[c] * star;                                                \
+        }                                                                                           \
     }
 
     for (int pass = 1; pass <= 2; ++pass) {
-        const bool first = pass == 1;
-        if (!first) {
+        if (pass == 2) {
             if (!P.fast_transport)
                 break; // NoSplitAdvection: the uniform pass is skipped (:646)
 #pragma unroll
-            for (int c = 0; c <= C; ++c)
+            for (int c = 0; c < C; ++c)
                 V[c] = vconst;
-        } else {
-            const double vr = __shfl(V[0], lsrc_r, 64);
-            V[C] = edge_r ? hV : vr;
         }
-        // per-interface upwind data shared by all quantities
-        bool up[C + 1];
-        double dist[C + 1];
+        // per-face upwind data shared by all quantities
+        bool up[C];
+        double dist[C];
 #pragma unroll
-        for (int k = 0; k <= C; ++k) {
-            const double ksi = V[k] * dt;
-            up[k] = ksi > 0.0;
-            dist[k] = up[k] ? (dxtheta - ksi) : -(dxtheta + ksi);
+        for (int c = 0; c < C; ++c) {
+            const double ksi = V[c] * dt;
+            up[c] = ksi > 0.0;
+            dist[c] = up[c] ? (dxtheta - ksi) : -(dxtheta + ksi);
         }
-        const bool uni_up = vconst * dt > 0.0;
-        double ext[C + 4], rho[C + 1], rS[C];
-        THETA_EXT(ext, S, hS[0], hS[1], first);
-        if (first) {
-            THETA_STARS(rho, ext, false, false);
-        } else if (uni_up) {
-            THETA_STARS(rho, ext, true, true);
-        } else {
-            THETA_STARS(rho, ext, true, false);
-        }
+        double rho[C], rS[C], dummy[C];
+        THETA_FLUX(dummy, rho, S, dummy, true); // DensityStar at the lower faces
 #pragma unroll
         for (int c = 0; c < C; ++c)
             rS[c] = fast_rcp(S[c]);
-#define THETA_Q(X, INP)                                                                              \
-        {                                                                                            \
-            double W[C], we[C + 4], qs[C + 1], fl[C + 1];                                            \
-            _Pragma("unroll") for (int c = 0; c < C; ++c) W[c] = X[c] * rS[c];                       \
-            double e0 = 0.0, e1 = 0.0;                                                               \
-            if (first && (edge_l || edge_r)) {                                                       \
-                e0 = INP[hG[0]] * hR[0];                                                             \
-                e1 = INP[hG[1]] * hR[1];                                                             \
-            }                                                                                        \
-            THETA_EXT(we, W, e0, e1, first);                                                         \
-            if (first) {                                                                             \
-                THETA_STARS(qs, we, false, false);                                                   \
-            } else if (uni_up) {                                                                     \
-                THETA_STARS(qs, we, true, true);                                                     \
-            } else {                                                                                 \
-                THETA_STARS(qs, we, true, false);                                                    \
-            }                                                                                        \
-            _Pragma("unroll") for (int k = 0; k <= C; ++k) fl[k] = dxrad * qs[k] * rho[k] * V[k];    \
-            _Pragma("unroll") for (int c = 0; c < C; ++c)                                            \
-            {                                                                                        \
-                double varq = fl[c];                                                                 \
-                varq -= fl[c + 1];                                                                   \
-                X[c] += varq * invsurf;                                                              \
-            }                                                                                        \
+        // varq = dxrad * Q* * rho* * v  (:655-658), evaluated as ((dxrad Q*) rho*) v
+#define THETA_Q(X)                                                                                  \
+        {                                                                                           \
+            double W[C], fl[C + 1], qs[C];                                                          \
+            _Pragma("unroll") for (int c = 0; c < C; ++c) W[c] = X[c] * rS[c];                      \
+            THETA_FLUX(fl, qs, W, dummy, true);                                                     \
+            _Pragma("unroll") for (int c = 0; c < C; ++c) fl[c] = dxrad * qs[c] * rho[c] * V[c];    \
+            fl[C] = __shfl(fl[0], lsrc_r, 64);                                                      \
+            _Pragma("unroll") for (int c = 0; c < C; ++c)                                           \
+            {                                                                                       \
+                double varq = fl[c];                                                                \
+                varq -= fl[c + 1];                                                                  \
+                X[c] += varq * invsurf;                                                             \
+            }                                                                                       \
         }
-        THETA_Q(Q[0], in.rmp);
-        THETA_Q(Q[1], in.rmm);
-        THETA_Q(Q[2], in.lp);
-        THETA_Q(Q[3], in.lm);
+        THETA_Q(Q[0]);
+        THETA_Q(Q[1]);
+        THETA_Q(Q[2]);
+        THETA_Q(Q[3]);
         if (ADI)
-            THETA_Q(E, in.e);
+            THETA_Q(E);
         {
             double fl[C + 1];
 #pragma unroll
-            for (int k = 0; k <= C; ++k)
-                fl[k] = dxrad * 1.0 * rho[k] * V[k];
+            for (int c = 0; c < C; ++c)
+                fl[c] = dxrad * 1.0 * rho[c] * V[c];
+            fl[C] = __shfl(fl[0], lsrc_r, 64);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 double varq = fl[c];
@@ -1508,15 +1469,14 @@ __global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, Thet
         }
 #undef THETA_Q
     }
-#undef THETA_STARS
-#undef THETA_EXT
+#undef THETA_FLUX
     // AdvectSHIFT (:238-268): cell j lands in j + Nshift (Nshift folded into [0, nphi) once)
     int nshift = P.nshift_c[i] % nphi;
     nshift = nshift < 0 ? nshift + nphi : nshift;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const int pos = lane * C + c;
-        const bool valid = act && (periodic == 1 || (pos >= 2 && pos < 64 * C - 2));
+        const bool valid = act && (periodic || (pos >= THETA_HALO && pos < 64 * C - THETA_HALO));
         if (valid) {
             const int g = row + wrap(idx[c] + nshift);
             out.sig[g] = S[c];
@@ -1909,24 +1869,22 @@ void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
     ThetaOut outB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     // fused azimuthal sweep when a lane-chunk size fits the ring, else the two-pass kernels
     int C = 0, periodic = 0;
-    for (int c : {2, 4, 6})
-        if (!C && P.nphi % c == 0 && P.nphi <= 64 * c) {
+    for (int c : {1, 2, 4})
+        if (!C && P.nphi % c == 0 && P.nphi <= 64 * c && (c == 1 || P.nphi / c >= 1)) {
             C = c;
             periodic = 1;
         }
     if (!C && P.nphi > 64 * 2)
-        C = 2; // measured on MI355X at Nphi = 4096: C = 2 / 4 / 6 -> 0.195 / 0.280 / 0.358 ms (occupancy wins)
+        C = 2;
     if (const char *e = getenv("FCPT_THETA_C")) // tuning knob: cells per lane in tiled mode
-        if (!periodic && (e[0] == '2' || e[0] == '4' || e[0] == '6') && P.nphi > 64 * (e[0] - '0'))
+        if (!periodic && (e[0] == '1' || e[0] == '2' || e[0] == '4') && P.nphi > 64 * (e[0] - '0'))
             C = e[0] - '0';
-    if (const char *e = getenv("FCPT_THETA_FUSED")) {
+    if (const char *e = getenv("FCPT_THETA_FUSED"))
         if (e[0] == '0')
             C = 0;
-        if (e[0] == 'x' && !periodic)
-            periodic = 2; // timing experiment only (wrong results): coalesced cell assignment
-    }
     if (C) {
-        const int tiles = periodic == 1 ? 1 : (P.nphi + (64 * C - 4) - 1) / (64 * C - 4);
+        const int tstride = 64 * C - 2 * THETA_HALO;
+        const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
         const int waves = P.nr * tiles;
         const dim3 grid((waves + 3) / 4), block(256);
 #define FUSED(CC)                                                                                      \
@@ -1934,12 +1892,12 @@ void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         KLAUNCH(KID_THETA1, (k_transport_theta_fused<CC, true>), grid, block, P, inB, outA, tiles, periodic); \
     else                                                                                               \
         KLAUNCH(KID_THETA1, (k_transport_theta_fused<CC, false>), grid, block, P, inB, outA, tiles, periodic);
-        if (C == 2) {
+        if (C == 1) {
+            FUSED(1)
+        } else if (C == 2) {
             FUSED(2)
-        } else if (C == 4) {
-            FUSED(4)
         } else {
-            FUSED(6)
+            FUSED(4)
         }
 #undef FUSED
         if (W.damp_in_step)
