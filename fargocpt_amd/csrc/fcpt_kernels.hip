@@ -1546,6 +1546,239 @@ template <bool DAMP, bool ROWU> __global__ void k_velocities(const Dev P, ThetaS
 }
 
 // ---------------------------------------------------------------------------
+// Azimuthal transport + velocities + floors + wave damping in ONE kernel, marching over rings.
+// As k_transport_theta_fused, but a wavefront owns a phi segment in POST-shift coordinates and
+// walks THETA_ROWS rings outward: for ring i it reads the cells that the integer shift maps
+// onto its segment (input index = output index - Nshift[i]), runs both passes in registers,
+// and -- because ring i-1 was processed by the same lanes one iteration earlier -- forms
+//   v_r(i)   = (rm+(i-1) + rm-(i)) / (Sigma(i-1) + Sigma(i))                (:515-523)
+//   v_phi(i) = (L+(j-1) + L-(j)) / (Sigma(j-1) + Sigma(j)) / r - r Omega    (:526-532)
+// applies the density floor / temperature range (:121-131) and the reference/zero wave damping
+// of the final boundary call, and stores the new state.  The transported momenta never go to
+// memory: the sweep reads 6 (7) grids and writes 3 (4) instead of 11 + 8 (13 + 10) doubles per
+// cell for k_transport_theta_fused + k_velocities.
+// Validity: 4 cells at either end of a segment are lost to the two passes, one more on the
+// left to the L+(j-1) neighbour.
+#define THETA_ROWS 16
+#define THETA_LO 5
+#define THETA_HI 4
+template <int C, bool ADI, bool DAMP>
+__global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const Dev W, ThetaSet in,
+                                                              int tiles, int periodic, int rows)
+{
+    // P: view whose vazi is the pre-transport v_phi; W: view that receives the new state
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int chunk = wave / tiles;
+    const int r0 = chunk * rows;
+    const int nr = P.nr;
+    if (r0 >= nr)
+        return;
+    const int r1 = r0 + rows < nr ? r0 + rows : nr;
+    const int tile = wave - chunk * tiles;
+    const int nphi = P.nphi;
+    const int nl = periodic ? nphi / C : 64;
+    const int stride = periodic ? nphi : 64 * C - (THETA_LO + THETA_HI);
+    const int a = periodic ? 0 : tile * stride - THETA_LO; // first (output) cell of the segment
+    const bool act = lane < nl;
+    const int ln = act ? lane : 0;
+    int lsrc_l = ln - 1, lsrc_r = ln + 1;
+    if (periodic) {
+        lsrc_l = lsrc_l < 0 ? nl - 1 : lsrc_l;
+        lsrc_r = lsrc_r >= nl ? 0 : lsrc_r;
+    } else {
+        lsrc_l = lsrc_l < 0 ? 0 : lsrc_l;
+        lsrc_r = lsrc_r > 63 ? 63 : lsrc_r;
+    }
+    const double dt = P.clk->dt;
+    auto wrap = [nphi](int j) { return j < 0 ? j + nphi : (j >= nphi ? j - nphi : j); };
+
+    int jout[C];
+    bool valid[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int pos = lane * C + c;
+        jout[c] = wrap(a + ln * C + c);
+        valid[c] = act && (periodic || (pos >= THETA_LO && pos < 64 * C - THETA_HI && a + pos < nphi));
+    }
+    double rmp_prev[C], S_prev[C]; // transported rm+ and Sigma of ring i-1 at the same output cells
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        rmp_prev[c] = S_prev[c] = 0.0;
+
+#define THETA_FLUX(st, W_)                                                                          \
+    {                                                                                               \
+        const double wl = __shfl(W_[C - 1], lsrc_l, 64); /* cell -1 */                              \
+        const double wr = __shfl(W_[0], lsrc_r, 64);     /* cell C  */                              \
+        double dq[C];                                                                               \
+        _Pragma("unroll") for (int c = 0; c < C; ++c)                                               \
+        {                                                                                           \
+            const double wm = c == 0 ? wl : W_[c == 0 ? 0 : c - 1];                                \
+            const double wp = c == C - 1 ? wr : W_[c == C - 1 ? C - 1 : c + 1];                     \
+            dq[c] = 0.5 * limiter(P.limiter, wp - W_[c], W_[c] - wm) * invdxtheta;                  \
+        }                                                                                           \
+        const double dql = __shfl(dq[C - 1], lsrc_l, 64); /* slope of cell -1 */                    \
+        _Pragma("unroll") for (int c = 0; c < C; ++c)                                               \
+        {                                                                                           \
+            const double xa = up[c] ? (c == 0 ? wl : W_[c == 0 ? 0 : c - 1]) : W_[c];               \
+            const double sl = up[c] ? (c == 0 ? dql : dq[c == 0 ? 0 : c - 1]) : dq[c];              \
+            st[c] = xa + dist[c] * sl;                                                              \
+        }                                                                                           \
+    }
+
+    // software prefetch: the inputs of ring i+1 are requested while ring i is computed
+    struct RingIn {
+        double s, rmp, rmm, lp, lm, e, va;
+    };
+    auto ring_load = [&](int ii, RingIn *r) {
+        const int rrow = ii * nphi;
+        int ns = P.nshift_c[ii] % nphi;
+        ns = ns < 0 ? ns + nphi : ns;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int g = rrow + wrap(jout[c] - ns); // the cell that AdvectSHIFT moves onto jout
+            r[c].s = in.sig[g];
+            r[c].rmp = in.rmp[g];
+            r[c].rmm = in.rmm[g];
+            r[c].lp = in.lp[g];
+            r[c].lm = in.lm[g];
+            r[c].e = ADI ? in.e[g] : 0.0;
+            r[c].va = P.vazi[g];
+        }
+    };
+    const int i0 = r0 > 0 ? r0 - 1 : 0;
+    RingIn nxt[C];
+    ring_load(i0, nxt);
+    for (int i = i0; i < r1; ++i) {
+        const int row = i * nphi;
+        const double mean = P.vmean_c[i];
+        const double vconst = P.vconst_c[i];
+        const double vadd = P.fast_transport ? 0.0 : vconst;
+        double S[C], Q[4][C], E[C], V[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            S[c] = nxt[c].s;
+            Q[0][c] = nxt[c].rmp;
+            Q[1][c] = nxt[c].rmm;
+            Q[2][c] = nxt[c].lp;
+            Q[3][c] = nxt[c].lm;
+            E[c] = nxt[c].e;
+            V[c] = vadd + (nxt[c].va - mean);
+        }
+        if (i + 1 < r1)
+            ring_load(i + 1, nxt);
+        const double dxtheta = P.dphi * P.Rmed[i];
+        const double invdxtheta = 1.0 / dxtheta;
+        const double dxrad = (P.Rsup[i] - P.Rinf[i]) * dt;
+        const double invsurf = P.InvSurf[i];
+        for (int pass = 1; pass <= 2; ++pass) {
+            if (pass == 2) {
+                if (!P.fast_transport)
+                    break;
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    V[c] = vconst;
+            }
+            bool up[C];
+            double dist[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double ksi = V[c] * dt;
+                up[c] = ksi > 0.0;
+                dist[c] = up[c] ? (dxtheta - ksi) : -(dxtheta + ksi);
+            }
+            double rho[C], rS[C];
+            THETA_FLUX(rho, S);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                rS[c] = fast_rcp(S[c]);
+#define THETA_Q(X)                                                                                  \
+            {                                                                                       \
+                double Wq[C], fl[C + 1], qs[C];                                                     \
+                _Pragma("unroll") for (int c = 0; c < C; ++c) Wq[c] = X[c] * rS[c];                 \
+                THETA_FLUX(qs, Wq);                                                                 \
+                _Pragma("unroll") for (int c = 0; c < C; ++c) fl[c] = dxrad * qs[c] * rho[c] * V[c]; \
+                fl[C] = __shfl(fl[0], lsrc_r, 64);                                                  \
+                _Pragma("unroll") for (int c = 0; c < C; ++c)                                       \
+                {                                                                                   \
+                    double varq = fl[c];                                                            \
+                    varq -= fl[c + 1];                                                              \
+                    X[c] += varq * invsurf;                                                         \
+                }                                                                                   \
+            }
+            THETA_Q(Q[0]);
+            THETA_Q(Q[1]);
+            THETA_Q(Q[2]);
+            THETA_Q(Q[3]);
+            if (ADI)
+                THETA_Q(E);
+            {
+                double fl[C + 1];
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    fl[c] = dxrad * 1.0 * rho[c] * V[c];
+                fl[C] = __shfl(fl[0], lsrc_r, 64);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    double varq = fl[c];
+                    varq -= fl[c + 1];
+                    S[c] += varq * invsurf;
+                }
+            }
+#undef THETA_Q
+        }
+        // compute_velocities_from_momenta + floors + damping for ring i (rings < r0 only prime rmp/S)
+        if (i >= r0) {
+            const double lp_l = __shfl(Q[2][C - 1], lsrc_l, 64); // L+ and Sigma of cell j-1
+            const double s_l = __shfl(S[C - 1], lsrc_l, 64);
+            const double fs = DAMP ? W.dfac_s[i] : 0.0, ts = DAMP ? W.dtau_s[i] : 1.0;
+            const int tvr = DAMP ? W.dtype_vr[i] : 0, tva = DAMP ? W.dtype_va[i] : 0;
+            const int tsg = DAMP ? W.dtype_sig[i] : 0, ten = DAMP ? W.dtype_e[i] : 0;
+            const double fv = DAMP ? W.dfac_v[i] : 0.0, tv = DAMP ? W.dtau_v[i] : 1.0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double lpm = c == 0 ? lp_l : Q[2][c == 0 ? 0 : c - 1];
+                const double sm = c == 0 ? s_l : S[c == 0 ? 0 : c - 1];
+                double vr = 0.0;
+                if (i != 0)
+                    vr = (rmp_prev[c] + Q[1][c]) / (S_prev[c] + S[c]);
+                double va = (lpm + Q[3][c]) / (sm + S[c]) * P.InvRmed[i] - P.Rmed[i] * P.omega_frame;
+                double sf = S[c] < P.sigma_floor_abs ? P.sigma_floor_abs : S[c];
+                double e = ADI ? clamp_energy(P, E[c], sf) : 0.0;
+                const int g = row + jout[c];
+                if (DAMP) {
+                    vr = damp_value(W, vr, tvr, fv, tv, dt, W.vrad0, g, 0.0);
+                    va = damp_value(W, va, tva, fs, ts, dt, W.vazi0, g, 0.0);
+                    sf = damp_value(W, sf, tsg, fs, ts, dt, W.sigma0, g, W.sigma_floor_abs);
+                    if (ADI)
+                        e = damp_value(W, e, ten, fs, ts, dt, W.energy0, g, 0.0);
+                }
+                if (valid[c]) {
+                    W.vrad[g] = vr;
+                    W.vazi[g] = va;
+                    W.sigma[g] = sf;
+                    if (ADI)
+                        W.energy[g] = e;
+                    if (i == nr - 1) { // v_r row Nr is not transported: it keeps its post-boundary value
+                        double v = P.vrad[nr * nphi + jout[c]];
+                        if (DAMP)
+                            v = damp_value(W, v, W.dtype_vr[nr], W.dfac_v[nr], W.dtau_v[nr], dt, W.vrad0,
+                                           nr * nphi + jout[c], 0.0);
+                        W.vrad[nr * nphi + jout[c]] = v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            rmp_prev[c] = Q[0][c];
+            S_prev[c] = S[c];
+        }
+    }
+#undef THETA_FLUX
+}
+
+// ---------------------------------------------------------------------------
 // cfl.cpp:185-376 condition_cfl.  k_ring_mean gives <v_phi>.  dt_cell = CFL / sqrt(sum of
 // the squared inverse limits) and both sqrt and the quotient are monotone, so
 // min_cells dt_cell == CFL / sqrt(max_cells sum): k_cfl_cells reduces the per-cell sums to one
@@ -1882,7 +2115,42 @@ void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
     if (const char *e = getenv("FCPT_THETA_FUSED"))
         if (e[0] == '0')
             C = 0;
-    if (C) {
+    bool march = C != 0;
+    if (const char *e = getenv("FCPT_THETA_MARCH"))
+        march = march && e[0] != '0';
+    if (march) {
+        const int tstride = 64 * C - (THETA_LO + THETA_HI);
+        const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
+        int rows = THETA_ROWS;
+        if (const char *e = getenv("FCPT_THETA_ROWS"))
+            rows = atoi(e) > 0 ? atoi(e) : rows;
+        const int chunks = (P.nr + rows - 1) / rows;
+        const int waves = chunks * tiles;
+        const dim3 grid((waves + 3) / 4), block(256);
+#define MARCHK(CC, AA, DD) \
+    KLAUNCH(KID_THETA1, (k_transport_theta_march<CC, AA, DD>), grid, block, P, W, inB, tiles, periodic, rows)
+#define MARCHC(CC)                     \
+    if (P.adiabatic) {                 \
+        if (W.damp_in_step)            \
+            MARCHK(CC, true, true);    \
+        else                           \
+            MARCHK(CC, true, false);   \
+    } else {                           \
+        if (W.damp_in_step)            \
+            MARCHK(CC, false, true);   \
+        else                           \
+            MARCHK(CC, false, false);  \
+    }
+        if (C == 1) {
+            MARCHC(1)
+        } else if (C == 2) {
+            MARCHC(2)
+        } else {
+            MARCHC(4)
+        }
+#undef MARCHC
+#undef MARCHK
+    } else if (C) {
         const int tstride = 64 * C - 2 * THETA_HALO;
         const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
         const int waves = P.nr * tiles;
