@@ -130,6 +130,7 @@ DampRange damp_range(const fcpt_ctx *c, int is_vector, int type, int outer)
 void apply_boundary_view(fcpt_ctx *c, const Dev &P, bool final, bool damping_done = false)
 {
     if (final && c->d.damping && !damping_done) {
+        c->P.cfl_ring_nparts = 0; // v_phi changes below: the ring sums left by the transport are stale
         // damping.cpp:754-774, order of damping_vector: vrad, vaz, sigma, energy
         for (int o = 0; o < 2; ++o)
             launch_damping(P, P.vrad, P.vrad0, P.Rinf.p, c->damp[0][o], 0, c->stream);
@@ -183,8 +184,10 @@ void enqueue_step(fcpt_ctx *c)
         launch_potential(P, st); // CalculateNbodyPotential; static when H and the bodies are
         c->potential_valid = true;
     }
+    int marched = 0;
     if (c->fused_source) {
-        if (!(c->march_source && launch_source_march(P, st))) { // one pass: (v) -> (v_b)
+        const int segs = c->march_source ? launch_source_march(P, st) : 0; // one pass: (v) -> (v_b)
+        if (!segs) {
             ensure_pressure(c);
             launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
             launch_recalculate_viscosity(P, st);
@@ -195,8 +198,10 @@ void enqueue_step(fcpt_ctx *c)
         Dev Q = P; // view with the post-source velocities
         Q.vrad = P.vrad_b;
         Q.vazi = P.vazi_b;
+        Q.src_ring_nparts = 0; // (per-segment partial sums were measured slower than the k_ring_mean pass)
+        (void)segs;
         apply_boundary_view(c, Q, false);
-        launch_transport(Q, P, st);
+        marched = launch_transport(Q, P, st);
     } else {
         ensure_pressure(c);
         launch_source(P, st);
@@ -207,9 +212,13 @@ void enqueue_step(fcpt_ctx *c)
         if (P.adiabatic)
             launch_substep3(P, 1, st);
         apply_boundary(c, false);
-        launch_transport(P, P, st);
+        Dev Q = P;
+        Q.src_ring_nparts = 0;
+        marched = launch_transport(Q, P, st);
     }
-    launch_clock_advance(P.clk, st);
+    c->P.cfl_ring_nparts = 0; // (partial ring sums from the marching kernels: disabled)
+    if (!marched)
+        launch_clock_advance(P.clk, st);
     c->stepped = true;
 }
 
@@ -351,6 +360,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     AL(rmpB, ns) AL(rmmB, ns) AL(lpB, ns) AL(lmB, ns) AL(sigB, ns) AL(eB, ns)
     AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1)
     AL(cfl_part, (size_t)(nr + 256) * (size_t)((nphi + 255) / 256 + 1))
+    P.ring_pstride = nphi / 32 + 4;
+    AL(ring_part, (size_t)nr * P.ring_pstride) AL(cfl_ring_part, (size_t)nr * P.ring_pstride)
 #undef AL
     if (!rc && hipHostMalloc((void **)&c->h_clk, sizeof(DevClock)) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -596,6 +607,8 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
     HIPCHK(hipStreamSynchronize(c->stream));
     if (f == FCPT_F_SCALE_HEIGHT)
         c->potential_valid = false;
+    if (f == FCPT_F_VAZI)
+        c->P.cfl_ring_nparts = 0;
     return FCPT_OK;
 }
 
@@ -683,7 +696,7 @@ int fcpt_cfl(fcpt_ctx *c, double *dt_local)
     if (!c || !dt_local)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    launch_cfl(c->P, c->stream);
+    launch_cfl(c->P, 0, c->P.cfl_ring_nparts > 0, c->stream);
     HIPCHK(hipGetLastError());
     DevClock k;
     if (int rc = read_clock(c, &k))
@@ -699,7 +712,7 @@ int fcpt_cfl_device(fcpt_ctx *c, double *d_dt_local)
     if (!c || !d_dt_local)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    launch_cfl(c->P, c->stream);
+    launch_cfl(c->P, 0, c->P.cfl_ring_nparts > 0, c->stream);
     launch_clock_export_cfl(c->P.clk, d_dt_local, c->stream);
     HIPCHK(hipGetLastError());
     return FCPT_OK;
@@ -895,8 +908,7 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
     if (!snap) {
         // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
         for (; n < nsteps; ++n) {
-            launch_cfl(c->P, c->stream);
-            launch_clock_policy(c->P.clk, c->d.cfl_max_var, 1, 0.0, c->stream);
+            launch_cfl(c->P, 1, c->P.cfl_ring_nparts > 0, c->stream); // CFL + CalculateTimeStep policy on the device
             enqueue_step(c);
             enqueue_post(c);
         }

@@ -42,15 +42,15 @@ void launch_substep3(const Dev &P, int update_energy, hipStream_t st);
 void launch_boundary(const Dev &P, hipStream_t st);
 void launch_damping(const Dev &P, double *q, double *q0, const double *radius, const DampRange &r,
                     int is_density, hipStream_t st);
-void launch_transport(const Dev &P, const Dev &W, hipStream_t st);
+int launch_transport(const Dev &P, const Dev &W, hipStream_t st);
 void launch_source_fused(const Dev &P, hipStream_t st);
-bool launch_source_march(const Dev &P, hipStream_t st);
+int launch_source_march(const Dev &P, hipStream_t st);
 void launch_viscous_fused(const Dev &P, hipStream_t st);
 void launch_substep3_after_fused(const Dev &P, hipStream_t st);
 void launch_derived(const Dev &P, hipStream_t st);
 void launch_pressure(const Dev &P, hipStream_t st);
 void launch_temperature(const Dev &P, hipStream_t st);
-void launch_cfl(const Dev &P, hipStream_t st);
+void launch_cfl(const Dev &P, int apply_policy, int use_part, hipStream_t st);
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st);
 void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st);
 void launch_clock_policy_ptr(DevClock *clk, double cfl_max_var, const double *cfl_global, hipStream_t st);

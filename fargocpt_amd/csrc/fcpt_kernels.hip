@@ -1184,12 +1184,23 @@ template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(c
 
 // compute_average_azimuthal_velocity (:174-189) + ComputeConstantResidual (:207-236):
 // one block per ring; wavefront shuffles + LDS for the ring sum.
-__global__ void k_ring_mean(const Dev P, int with_shift)
+__global__ void k_ring_mean(const Dev P, int with_shift, const double *part, int nparts, int pstride)
 {
+    // part != nullptr: the producer kernel left nparts partial sums per ring (fixed order, so the
+    // result is deterministic); rings rewritten afterwards by a boundary condition are re-summed
+    // from the grid.
     const int i = blockIdx.x;
+    const bool ghost = (i == 0 && P.is_first && P.bc_vaz[0] != FCPT_BC_NONE) ||
+                       (i == P.nr - 1 && P.is_last && P.bc_vaz[1] != FCPT_BC_NONE) ||
+                       (!P.is_first && i < FCPT_OVERLAP) || (!P.is_last && i >= P.nr - FCPT_OVERLAP);
     double acc = 0.0;
-    for (int j = threadIdx.x; j < P.nphi; j += blockDim.x)
-        acc += P.vazi[IDX(i, j)];
+    if (part && !ghost) {
+        for (int n = threadIdx.x; n < nparts; n += blockDim.x)
+            acc += part[i * pstride + n];
+    } else {
+        for (int j = threadIdx.x; j < P.nphi; j += blockDim.x)
+            acc += P.vazi[IDX(i, j)];
+    }
     for (int off = 32; off > 0; off >>= 1)
         acc += __shfl_down(acc, off, 64);
     __shared__ double s_w[4];
@@ -1559,14 +1570,14 @@ template <bool DAMP, bool ROWU> __global__ void k_velocities(const Dev P, ThetaS
 // cell for k_transport_theta_fused + k_velocities.
 // Validity: 4 cells at either end of a segment are lost to the two passes, one more on the
 // left to the L+(j-1) neighbour.
-#define THETA_ROWS 16
+#define THETA_ROWS 8
 #define THETA_LO 5
 #define THETA_HI 4
 template <int C, bool ADI, bool DAMP>
-__global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const Dev W, ThetaSet in,
-                                                              int tiles, int periodic, int rows)
+__global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const double *va_pre, const double *vr_pre, ThetaSet in,
+                                                              int tiles, int periodic, int rows, int advance_clock)
 {
-    // P: view whose vazi is the pre-transport v_phi; W: view that receives the new state
+    // va_pre / vr_pre: the pre-transport (post-source, post-boundary) velocities; the new state goes to P's grids
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chunk = wave / tiles;
@@ -1626,7 +1637,6 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
         }                                                                                           \
     }
 
-    // software prefetch: the inputs of ring i+1 are requested while ring i is computed
     struct RingIn {
         double s, rmp, rmm, lp, lm, e, va;
     };
@@ -1643,13 +1653,13 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
             r[c].lp = in.lp[g];
             r[c].lm = in.lm[g];
             r[c].e = ADI ? in.e[g] : 0.0;
-            r[c].va = P.vazi[g];
+            r[c].va = va_pre[g];
         }
     };
     const int i0 = r0 > 0 ? r0 - 1 : 0;
-    RingIn nxt[C];
-    ring_load(i0, nxt);
     for (int i = i0; i < r1; ++i) {
+        RingIn nxt[C];
+        ring_load(i, nxt);
         const int row = i * nphi;
         const double mean = P.vmean_c[i];
         const double vconst = P.vconst_c[i];
@@ -1665,8 +1675,6 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
             E[c] = nxt[c].e;
             V[c] = vadd + (nxt[c].va - mean);
         }
-        if (i + 1 < r1)
-            ring_load(i + 1, nxt);
         const double dxtheta = P.dphi * P.Rmed[i];
         const double invdxtheta = 1.0 / dxtheta;
         const double dxrad = (P.Rsup[i] - P.Rinf[i]) * dt;
@@ -1731,10 +1739,10 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
         if (i >= r0) {
             const double lp_l = __shfl(Q[2][C - 1], lsrc_l, 64); // L+ and Sigma of cell j-1
             const double s_l = __shfl(S[C - 1], lsrc_l, 64);
-            const double fs = DAMP ? W.dfac_s[i] : 0.0, ts = DAMP ? W.dtau_s[i] : 1.0;
-            const int tvr = DAMP ? W.dtype_vr[i] : 0, tva = DAMP ? W.dtype_va[i] : 0;
-            const int tsg = DAMP ? W.dtype_sig[i] : 0, ten = DAMP ? W.dtype_e[i] : 0;
-            const double fv = DAMP ? W.dfac_v[i] : 0.0, tv = DAMP ? W.dtau_v[i] : 1.0;
+            const double fs = DAMP ? P.dfac_s[i] : 0.0, ts = DAMP ? P.dtau_s[i] : 1.0;
+            const int tvr = DAMP ? P.dtype_vr[i] : 0, tva = DAMP ? P.dtype_va[i] : 0;
+            const int tsg = DAMP ? P.dtype_sig[i] : 0, ten = DAMP ? P.dtype_e[i] : 0;
+            const double fv = DAMP ? P.dfac_v[i] : 0.0, tv = DAMP ? P.dtau_v[i] : 1.0;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const double lpm = c == 0 ? lp_l : Q[2][c == 0 ? 0 : c - 1];
@@ -1747,24 +1755,24 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
                 double e = ADI ? clamp_energy(P, E[c], sf) : 0.0;
                 const int g = row + jout[c];
                 if (DAMP) {
-                    vr = damp_value(W, vr, tvr, fv, tv, dt, W.vrad0, g, 0.0);
-                    va = damp_value(W, va, tva, fs, ts, dt, W.vazi0, g, 0.0);
-                    sf = damp_value(W, sf, tsg, fs, ts, dt, W.sigma0, g, W.sigma_floor_abs);
+                    vr = damp_value(P, vr, tvr, fv, tv, dt, P.vrad0, g, 0.0);
+                    va = damp_value(P, va, tva, fs, ts, dt, P.vazi0, g, 0.0);
+                    sf = damp_value(P, sf, tsg, fs, ts, dt, P.sigma0, g, P.sigma_floor_abs);
                     if (ADI)
-                        e = damp_value(W, e, ten, fs, ts, dt, W.energy0, g, 0.0);
+                        e = damp_value(P, e, ten, fs, ts, dt, P.energy0, g, 0.0);
                 }
                 if (valid[c]) {
-                    W.vrad[g] = vr;
-                    W.vazi[g] = va;
-                    W.sigma[g] = sf;
+                    P.vrad[g] = vr;
+                    P.vazi[g] = va;
+                    P.sigma[g] = sf;
                     if (ADI)
-                        W.energy[g] = e;
+                        P.energy[g] = e;
                     if (i == nr - 1) { // v_r row Nr is not transported: it keeps its post-boundary value
-                        double v = P.vrad[nr * nphi + jout[c]];
+                        double v = vr_pre[nr * nphi + jout[c]];
                         if (DAMP)
-                            v = damp_value(W, v, W.dtype_vr[nr], W.dfac_v[nr], W.dtau_v[nr], dt, W.vrad0,
+                            v = damp_value(P, v, P.dtype_vr[nr], P.dfac_v[nr], P.dtau_v[nr], dt, P.vrad0,
                                            nr * nphi + jout[c], 0.0);
-                        W.vrad[nr * nphi + jout[c]] = v;
+                        P.vrad[nr * nphi + jout[c]] = v;
                     }
                 }
             }
@@ -1775,6 +1783,10 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
             S_prev[c] = S[c];
         }
     }
+    if (wave == 0 && lane == 0 && advance_clock) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
+        P.clk->time += dt;
+        P.clk->n_hydro_iter += 1;
+    }
 #undef THETA_FLUX
 }
 
@@ -1784,50 +1796,58 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
 // min_cells dt_cell == CFL / sqrt(max_cells sum): k_cfl_cells reduces the per-cell sums to one
 // maximum per block (no atomics); k_cfl_final folds the block maxima, applies sqrt and the
 // quotient once, and adds the per-ring FARGO shear limit (:207-220).
+#define CFL_ROWS 8
+// One thread owns a phi column and walks CFL_ROWS rings (v_r(i+1) of one ring is v_r(i) of the
+// next, so every value is loaded once); per-block maxima, no atomics.
 template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i_ = P.first_active + blockIdx.y * blockDim.y + threadIdx.y;
-    const int i = ROWU ? __builtin_amdgcn_readfirstlane(i_) : i_;
+    const int r0_ = P.first_active + (blockIdx.y * blockDim.y + threadIdx.y) * CFL_ROWS;
+    const int r0 = ROWU ? __builtin_amdgcn_readfirstlane(r0_) : r0_;
     double s = 0.0;
-    if (j < P.nphi && i < P.active_size) {
+    if (j < P.nphi && r0 < P.active_size) {
         const int jn = JNEXT;
-        const double inv_dxr = P.InvDiffRsup[i];        // 1 / (Rsup - Rinf)
-        const double inv_dxa = P.InvRmed[i] * P.invdphi; // 1 / (Rmed dphi)
-        const double inv_cell = dmax(inv_dxr, inv_dxa); // 1 / min(dxRadial, dxAzimuthal)
+        const int r1 = r0 + CFL_ROWS < P.active_size ? r0 + CFL_ROWS : P.active_size;
         const double lf = P.leapfrog ? 0.6 : 1.0;
-        const double va = P.vazi[IDX(i, j)];
-        const double vres = P.fast_transport ? va - P.vmean_c[i] : va;
-        const double vr0 = P.vrad[IDX(i, j)], vr1 = P.vrad[IDX(i + 1, j)];
-        // isothermal: c_s and the alpha viscosity are per-ring constants (set once at init)
-        const double cs = P.adiabatic ? P.soundspeed[IDX(i, j)] : P.cs_ring[i];
-        const double nu = P.adiabatic ? P.viscosity[IDX(i, j)] : (P.alpha_viscosity ? P.nu_ring[i] : P.nu_const);
-        const double invdt1 = cs * inv_cell;
-        const double invdt2 = vr0 * inv_dxr;
-        const double invdt3 = vres * inv_dxa;
         const double C2 = P.art_visc_factor * P.art_visc_factor;
-        double invdt4;
-        if (P.art_visc == FCPT_ARTVISC_SN) {
-            double dvRadial = vr1 - vr0;
-            double dvAzimuthal = P.vazi[IDX(i, jn)] - va;
-            dvRadial = dvRadial > 0.0 ? 0.0 : -dvRadial;
-            dvAzimuthal = dvAzimuthal > 0.0 ? 0.0 : -dvAzimuthal;
-            invdt4 = 4.0 * C2 * dmax(dvRadial * inv_dxr, dvAzimuthal * inv_dxa) * lf;
-        } else { // the TW formula is also used for ArtificialViscosity: None (cfl.cpp:292)
-            const double eps_rr = (vr1 - vr0) * P.InvDiffRsup[i];
-            const double eps_pp =
-                P.InvRmed[i] * ((P.vazi[IDX(i, jn)] - va) * P.invdphi + 0.5 * (vr1 + vr0));
-            const double mdiv_V = -dmin(eps_rr + eps_pp, 0.0);
-            invdt4 = 4.0 * C2 * mdiv_V * lf;
+        double vr0 = P.vrad[IDX(r0, j)];
+        for (int i = r0; i < r1; ++i) {
+            const double vr1 = P.vrad[IDX(i + 1, j)];
+            const double inv_dxr = P.InvDiffRsup[i];         // 1 / (Rsup - Rinf)
+            const double inv_dxa = P.InvRmed[i] * P.invdphi; // 1 / (Rmed dphi)
+            const double inv_cell = dmax(inv_dxr, inv_dxa);  // 1 / min(dxRadial, dxAzimuthal)
+            const double va = P.vazi[IDX(i, j)];
+            const double van = P.vazi[IDX(i, jn)];
+            const double vres = P.fast_transport ? va - P.vmean_c[i] : va;
+            // isothermal: c_s and the alpha viscosity are per-ring constants (set once at init)
+            const double cs = P.adiabatic ? P.soundspeed[IDX(i, j)] : P.cs_ring[i];
+            const double nu = P.adiabatic ? P.viscosity[IDX(i, j)] : (P.alpha_viscosity ? P.nu_ring[i] : P.nu_const);
+            const double invdt1 = cs * inv_cell;
+            const double invdt2 = vr0 * inv_dxr;
+            const double invdt3 = vres * inv_dxa;
+            double invdt4;
+            if (P.art_visc == FCPT_ARTVISC_SN) {
+                double dvRadial = vr1 - vr0;
+                double dvAzimuthal = van - va;
+                dvRadial = dvRadial > 0.0 ? 0.0 : -dvRadial;
+                dvAzimuthal = dvAzimuthal > 0.0 ? 0.0 : -dvAzimuthal;
+                invdt4 = 4.0 * C2 * dmax(dvRadial * inv_dxr, dvAzimuthal * inv_dxa) * lf;
+            } else { // the TW formula is also used for ArtificialViscosity: None (cfl.cpp:292)
+                const double eps_rr = (vr1 - vr0) * P.InvDiffRsup[i];
+                const double eps_pp = P.InvRmed[i] * ((van - va) * P.invdphi + 0.5 * (vr1 + vr0));
+                const double mdiv_V = -dmin(eps_rr + eps_pp, 0.0);
+                invdt4 = 4.0 * C2 * mdiv_V * lf;
+            }
+            const double invdt5 = 4.0 * nu * (inv_cell * inv_cell) * lf;
+            double invdt6 = 0.0;
+            if (P.adiabatic) {
+                const double inv_limit = 1.0 / P.heating_cooling_cfl_limit;
+                invdt6 = inv_limit * fabs((P.qplus[IDX(i, j)] - P.qminus[IDX(i, j)]) / P.energy[IDX(i, j)]) * lf;
+            }
+            s = dmax(s, invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 + invdt5 * invdt5 +
+                            invdt6 * invdt6);
+            vr0 = vr1;
         }
-        const double invdt5 = 4.0 * nu * (inv_cell * inv_cell) * lf;
-        double invdt6 = 0.0;
-        if (P.adiabatic) {
-            const double inv_limit = 1.0 / P.heating_cooling_cfl_limit;
-            invdt6 = inv_limit * fabs((P.qplus[IDX(i, j)] - P.qminus[IDX(i, j)]) / P.energy[IDX(i, j)]) * lf;
-        }
-        s = invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 + invdt5 * invdt5 +
-            invdt6 * invdt6;
     }
     for (int off = 32; off > 0; off >>= 1)
         s = dmax(s, __shfl_down(s, off, 64));
@@ -1839,7 +1859,7 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
     if (tid == 0)
         part[blockIdx.y * gridDim.x + blockIdx.x] = dmax(dmax(s_w[0], s_w[1]), dmax(s_w[2], s_w[3]));
 }
-__global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *part, int nparts)
+__global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *part, int nparts, int apply_policy)
 {
     double smax = 0.0;
     for (int n = threadIdx.x; n < nparts; n += blockDim.x)
@@ -1871,6 +1891,13 @@ __global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *p
         if (nparts > 0)
             dt = dmin(dt, P.cfl / sqrt(smax));
         P.clk->cfl_bits = (unsigned long long)__double_as_longlong(dt);
+        if (apply_policy) { // sim::CalculateTimeStep (simulation.cpp:100-118) for single-slab device loops
+            const double a = P.cfl_max_var * P.clk->last_dt;
+            const double rv = dt < a ? dt : a;
+            P.clk->cfl_dt = rv;
+            P.clk->last_dt = rv;
+            P.clk->dt = rv;
+        }
     }
 }
 
@@ -2019,10 +2046,10 @@ void launch_source_fused(const Dev &P, hipStream_t st)
     LAUNCH2D(KID_TW_Q, k_av_fused, P.nr + 1, P);
 }
 // whole source step in one marching pass (isothermal, Nphi >= 128); returns false if not applicable
-bool launch_source_march(const Dev &P, hipStream_t st)
+int launch_source_march(const Dev &P, hipStream_t st)
 {
     if (P.adiabatic || P.nphi < 128)
-        return false;
+        return 0;
     const int rows = 32;
     const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
     const int chunks = (P.nr + 1 + rows - 1) / rows;
@@ -2034,7 +2061,7 @@ bool launch_source_march(const Dev &P, hipStream_t st)
         KLAUNCH(KID_SOURCE_VR, k_source_march<2>, grid, block, P, segs, rows);
     else
         KLAUNCH(KID_SOURCE_VR, k_source_march<0>, grid, block, P, segs, rows);
-    return true;
+    return segs;
 }
 void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_VR, k_visc_fused, P.nr + 1, P); }
 void launch_substep3_after_fused(const Dev &P, hipStream_t st)
@@ -2084,8 +2111,9 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
             r.redge, r.tau, is_density);
 }
 
-void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
+int launch_transport(const Dev &P, const Dev &W, hipStream_t st)
 {
+    int marched_tiles = 0; // > 0: the marching kernel ran (new state, clock advance and CFL partial sums done)
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     // Transport, TransportEuler.cpp:112-136
     {
@@ -2095,7 +2123,8 @@ void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         else
             KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, l.grid, l.block, P);
     }
-    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(256), P, 1);
+    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(P.src_ring_nparts ? 64 : 256), P, 1,
+            P.src_ring_nparts ? (const double *)P.ring_part : (const double *)nullptr, P.src_ring_nparts, P.ring_pstride);
     ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     ThetaOut outA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
     ThetaSet inA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
@@ -2126,9 +2155,11 @@ void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
             rows = atoi(e) > 0 ? atoi(e) : rows;
         const int chunks = (P.nr + rows - 1) / rows;
         const int waves = chunks * tiles;
+        marched_tiles = tiles;
         const dim3 grid((waves + 3) / 4), block(256);
 #define MARCHK(CC, AA, DD) \
-    KLAUNCH(KID_THETA1, (k_transport_theta_march<CC, AA, DD>), grid, block, P, W, inB, tiles, periodic, rows)
+    KLAUNCH(KID_THETA1, (k_transport_theta_march<CC, AA, DD>), grid, block, W, (const double *)P.vazi, (const double *)P.vrad, \
+            inB, tiles, periodic, rows, 1)
 #define MARCHC(CC)                     \
     if (P.adiabatic) {                 \
         if (W.damp_in_step)            \
@@ -2180,6 +2211,7 @@ void launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         else
             LAUNCH2D_T(KID_VELOCITIES, k_velocities, false, P.nr, W, inB, (const double *)P.vrad);
     }
+    return marched_tiles;
 }
 
 void launch_derived(const Dev &P, hipStream_t st)
@@ -2199,20 +2231,21 @@ void launch_derived(const Dev &P, hipStream_t st)
 void launch_pressure(const Dev &P, hipStream_t st) { LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P); }
 void launch_temperature(const Dev &P, hipStream_t st) { LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P); }
 
-void launch_cfl(const Dev &P, hipStream_t st)
+void launch_cfl(const Dev &P, int apply_policy, int use_part, hipStream_t st)
 {
-    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(256), P, 0);
+    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(use_part ? 64 : 256), P, 0,
+            use_part ? (const double *)P.cfl_ring_part : (const double *)nullptr, P.cfl_ring_nparts, P.ring_pstride);
     const int nrows = P.active_size - P.first_active;
     int nparts = 0;
     if (nrows > 0) {
-        const Launch2D l = launch2d(nrows, P.nphi);
+        const Launch2D l = launch2d((nrows + CFL_ROWS - 1) / CFL_ROWS, P.nphi);
         nparts = (int)(l.grid.x * l.grid.y);
         if (l.block.x >= 64)
             KLAUNCH(KID_CFL_CELLS, k_cfl_cells<true>, l.grid, l.block, P, P.cfl_part);
         else
             KLAUNCH(KID_CFL_CELLS, k_cfl_cells<false>, l.grid, l.block, P, P.cfl_part);
     }
-    KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, nparts);
+    KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, nparts, apply_policy);
 }
 
 void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st)
