@@ -15,7 +15,7 @@ from . import binding
 from .binding import (Clock, Context, Desc, FcptError, Library, Split)  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfargocpt_hip.so")
+LIB_PATH = os.environ.get("FCPT_LIB_PATH") or os.path.join(_HERE, "libfargocpt_hip.so")  # FCPT_LIB_PATH: tuning builds
 
 _lib = None
 
