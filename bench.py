@@ -35,6 +35,10 @@ ALGO_DOUBLES = {
     "k_transport_theta1": (11, 13),  # read 5(6) + vphi -> write 5(6)
     "k_transport_theta2": (10, 12),  # read 5(6) -> write 5(6) (shifted)
     "k_velocities": (8, 10),         # read 5(6) -> write vr,vphi,Sigma(,e)
+    "k_source_march": (6, 6),            # read Sigma,Phi,vr,vphi -> write vr,vphi (isothermal one-pass source step)
+    "k_transport_theta_fused": (11, 13),  # read 5(6) + vphi -> write 5(6), both passes + shift
+    "k_transport_theta_march": (9, 11),   # read 5(6) + vphi -> write vr,vphi,Sigma(,e): passes C and D of the model
+    "k_src_fused": (7, 7), "k_av_fused": (5, 7), "k_visc_fused": (6, 7),
     "k_source_vr": (6, 6), "k_source_va": (4, 4), "k_tw_q": (5, 6), "k_tw_va": (3, 3),
     "k_tw_vr": (4, 4), "k_stress_diag": (7, 7), "k_stress_rphi": (5, 5), "k_visc_va": (4, 4),
     "k_visc_vr": (5, 5), "k_cfl_cells": (4, 7), "k_pressure": (3, 2), "k_potential": (2, 2),

@@ -14,6 +14,7 @@ enum KernelId {
     KID_VISCOSITY, KID_PRESSURE, KID_TEMPERATURE, KID_STRESS_DIAG, KID_STRESS_RPHI, KID_VISC_VA,
     KID_VISC_VR, KID_QPLUS, KID_SUBSTEP3, KID_BOUNDARY, KID_DAMPING, KID_TRANSPORT_RADIAL,
     KID_RING_MEAN, KID_THETA1, KID_THETA2, KID_VELOCITIES, KID_CFL_INIT, KID_CFL_CELLS, KID_CLOCK,
+    KID_SRC_FUSED, KID_AV_FUSED, KID_VISC_FUSED, KID_SOURCE_MARCH, KID_THETA_FUSED, KID_THETA_MARCH,
     KID_COUNT
 };
 extern const char *const kKernelNames[KID_COUNT];

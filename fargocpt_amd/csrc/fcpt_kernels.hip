@@ -1942,7 +1942,8 @@ const char *const kKernelNames[KID_COUNT] = {
     "k_viscosity", "k_pressure", "k_temperature", "k_stress_diag", "k_stress_rphi", "k_visc_va",
     "k_visc_vr", "k_qplus_qminus", "k_substep3", "k_boundary", "k_damping", "k_transport_radial",
     "k_ring_mean", "k_transport_theta1", "k_transport_theta2", "k_velocities", "k_cfl_final",
-    "k_cfl_cells", "k_clock"};
+    "k_cfl_cells", "k_clock", "k_src_fused", "k_av_fused", "k_visc_fused", "k_source_march",
+    "k_transport_theta_fused", "k_transport_theta_march"};
 
 thread_local Profiler *g_prof = nullptr;
 
@@ -2042,28 +2043,30 @@ void launch_iso_cs_h(const Dev &P, const double *cs_ring, hipStream_t st)
 
 void launch_source_fused(const Dev &P, hipStream_t st)
 {
-    LAUNCH2D(KID_SOURCE_VR, k_src_fused, P.nr + 1, P);
-    LAUNCH2D(KID_TW_Q, k_av_fused, P.nr + 1, P);
+    LAUNCH2D(KID_SRC_FUSED, k_src_fused, P.nr + 1, P);
+    LAUNCH2D(KID_AV_FUSED, k_av_fused, P.nr + 1, P);
 }
 // whole source step in one marching pass (isothermal, Nphi >= 128); returns false if not applicable
 int launch_source_march(const Dev &P, hipStream_t st)
 {
     if (P.adiabatic || P.nphi < 128)
         return 0;
-    const int rows = 32;
+    int rows = 24; // measured at 2048x4096: 16 / 24 / 32 / 48 / 64 rings -> 0.133 / 0.132 / 0.141 / 0.152 / 0.188 ms
+    if (const char *e = getenv("FCPT_SOURCE_ROWS")) // tuning knob
+        rows = atoi(e) > 0 ? atoi(e) : rows;
     const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
     const int chunks = (P.nr + 1 + rows - 1) / rows;
     const int waves = segs * chunks;
     const dim3 grid((waves + 3) / 4), block(256);
     if (P.art_visc == FCPT_ARTVISC_TW)
-        KLAUNCH(KID_SOURCE_VR, k_source_march<1>, grid, block, P, segs, rows);
+        KLAUNCH(KID_SOURCE_MARCH, k_source_march<1>, grid, block, P, segs, rows);
     else if (P.art_visc == FCPT_ARTVISC_SN)
-        KLAUNCH(KID_SOURCE_VR, k_source_march<2>, grid, block, P, segs, rows);
+        KLAUNCH(KID_SOURCE_MARCH, k_source_march<2>, grid, block, P, segs, rows);
     else
-        KLAUNCH(KID_SOURCE_VR, k_source_march<0>, grid, block, P, segs, rows);
+        KLAUNCH(KID_SOURCE_MARCH, k_source_march<0>, grid, block, P, segs, rows);
     return segs;
 }
-void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_VR, k_visc_fused, P.nr + 1, P); }
+void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_FUSED, k_visc_fused, P.nr + 1, P); }
 void launch_substep3_after_fused(const Dev &P, hipStream_t st)
 {
     // SubStep3 (SourceEuler.cpp:956-1051) with Q+ already evaluated by k_visc_fused
@@ -2158,7 +2161,7 @@ int launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         marched_tiles = tiles;
         const dim3 grid((waves + 3) / 4), block(256);
 #define MARCHK(CC, AA, DD) \
-    KLAUNCH(KID_THETA1, (k_transport_theta_march<CC, AA, DD>), grid, block, W, (const double *)P.vazi, (const double *)P.vrad, \
+    KLAUNCH(KID_THETA_MARCH, (k_transport_theta_march<CC, AA, DD>), grid, block, W, (const double *)P.vazi, (const double *)P.vrad, \
             inB, tiles, periodic, rows, 1)
 #define MARCHC(CC)                     \
     if (P.adiabatic) {                 \
@@ -2188,9 +2191,9 @@ int launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         const dim3 grid((waves + 3) / 4), block(256);
 #define FUSED(CC)                                                                                      \
     if (P.adiabatic)                                                                                   \
-        KLAUNCH(KID_THETA1, (k_transport_theta_fused<CC, true>), grid, block, P, inB, outA, tiles, periodic); \
+        KLAUNCH(KID_THETA_FUSED, (k_transport_theta_fused<CC, true>), grid, block, P, inB, outA, tiles, periodic); \
     else                                                                                               \
-        KLAUNCH(KID_THETA1, (k_transport_theta_fused<CC, false>), grid, block, P, inB, outA, tiles, periodic);
+        KLAUNCH(KID_THETA_FUSED, (k_transport_theta_fused<CC, false>), grid, block, P, inB, outA, tiles, periodic);
         if (C == 1) {
             FUSED(1)
         } else if (C == 2) {

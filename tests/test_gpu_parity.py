@@ -134,3 +134,14 @@ def test_device_resident_dt_loop(product):
         assert other["time"] == states[0]["time"]
         for k in ("sigma", "vrad", "vazi"):
             assert np.array_equal(other[k], states[0][k]), k
+
+
+def test_weak_scaling_grid_four_slabs(product, oracle):
+    """bench.py's N > 1 configuration at reduced size: the log grid is extended outward
+    (rmax = rmin * 6.25^N) and split into N radial slabs; 4 HIP slabs vs 1 oracle slab."""
+    n = 4
+    d = setups.planet_disk(product, 4 * 40, 160)
+    d.rmax = d.rmin * (2.5 / 0.4) ** n
+    d.damping_time_radius_outer = d.rmax
+    _check(run_pair(product, oracle, d, 15, nslabs=(n, 1), bodies=setups.jupiter_bodies(d)),
+           ("sigma", "vrad", "vazi"))
