@@ -218,6 +218,11 @@ class Context:
         self._call("set_bodies", _i32(len(x)), _as_dp(x), _as_dp(y), _as_dp(m), _as_dp(rsm),
                    _f64(indirect[0]), _f64(indirect[1]))
 
+    def set_bodies_midstep(self, x, y, m, rsm=None):
+        x, y, m = (np.ascontiguousarray(v, dtype=np.float64) for v in (x, y, m))
+        rsm = np.zeros_like(x) if rsm is None else np.ascontiguousarray(rsm, dtype=np.float64)
+        self._call("set_bodies_midstep", _i32(len(x)), _as_dp(x), _as_dp(y), _as_dp(m), _as_dp(rsm))
+
     def init_physics(self):
         self._call("init_physics")
 

@@ -40,6 +40,9 @@ struct fcpt_ctx {
     bool march_source = true;
     bool stepped = false; // fcpt_step ran since the last fcpt_post
     bool pressure_valid = false;
+    // leapfrog: bodies at the mid-step time (simulation.cpp:359-366)
+    bool has_mid = false;
+    double mx[FCPT_MAX_BODIES], my[FCPT_MAX_BODIES], mm[FCPT_MAX_BODIES], mrsm[FCPT_MAX_BODIES];
 };
 
 namespace {
@@ -175,16 +178,12 @@ void ensure_pressure(fcpt_ctx *c)
     }
 }
 
-// the gas part of step_Euler up to Transport (simulation.cpp:167-217)
-void enqueue_step(fcpt_ctx *c)
+// one gas "kick" (source terms, artificial viscosity, viscosity, SubStep3) with the step length
+// currently in the device clock.  Returns true if the result is in (vrad_b, vazi_b).
+bool enqueue_kick(fcpt_ctx *c)
 {
     const Dev &P = c->P;
     hipStream_t st = c->stream;
-    if (P.adiabatic || !c->potential_valid) {
-        launch_potential(P, st); // CalculateNbodyPotential; static when H and the bodies are
-        c->potential_valid = true;
-    }
-    int marched = 0;
     if (c->fused_source) {
         const int segs = c->march_source ? launch_source_march(P, st) : 0; // one pass: (v) -> (v_b)
         if (!segs) {
@@ -195,30 +194,80 @@ void enqueue_step(fcpt_ctx *c)
         }
         if (P.adiabatic)
             launch_substep3_after_fused(P, st);
-        Dev Q = P; // view with the post-source velocities
+        return true;
+    }
+    ensure_pressure(c);
+    launch_source(P, st);
+    launch_artificial_viscosity(P, st);
+    launch_recalculate_viscosity(P, st);
+    launch_stress(P, st);
+    launch_viscous_update(P, st);
+    if (P.adiabatic)
+        launch_substep3(P, 1, st);
+    return false;
+}
+
+void enqueue_potential(fcpt_ctx *c, bool midstep)
+{
+    Dev &P = c->P;
+    if (midstep && c->has_mid) {
+        Dev M = P;
+        for (int k = 0; k < P.nbodies; ++k) {
+            M.bx[k] = c->mx[k];
+            M.by[k] = c->my[k];
+            M.bm[k] = c->mm[k];
+            M.brsm[k] = c->mrsm[k];
+        }
+        launch_potential(M, c->stream);
+        c->potential_valid = false; // the grid now holds the mid-step potential
+        return;
+    }
+    if (P.adiabatic || !c->potential_valid) {
+        launch_potential(P, c->stream); // CalculateNbodyPotential; static when H and the bodies are
+        c->potential_valid = true;
+    }
+}
+
+// the gas part of step_Euler up to Transport (simulation.cpp:167-217), or of step_LeapFrog
+// (simulation.cpp:316-393): kick 1/2 (dt/2), drift (dt), kick 2/2 (dt/2).  `dt_dev`: the step
+// length is already in the device clock (device-resident dt), else `dt` is written there.
+void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt)
+{
+    const Dev &P = c->P;
+    hipStream_t st = c->stream;
+    const bool frog = c->d.integrator == FCPT_INTEGRATOR_LEAPFROG;
+    if (frog)
+        launch_clock_scale_dt(P.clk, dt_dev ? 1 : 0, dt, 0.5, st); // dt <- step/2, keeps step in cfl_dt
+    else if (!dt_dev)
+        launch_clock_set_dt(P.clk, dt, st);
+    enqueue_potential(c, false);
+    const bool in_b = enqueue_kick(c);
+    Dev Q = P; // view with the post-kick velocities
+    if (in_b) {
         Q.vrad = P.vrad_b;
         Q.vazi = P.vazi_b;
-        Q.src_ring_nparts = 0; // (per-segment partial sums were measured slower than the k_ring_mean pass)
-        (void)segs;
-        apply_boundary_view(c, Q, false);
-        marched = launch_transport(Q, P, st);
-    } else {
-        ensure_pressure(c);
-        launch_source(P, st);
-        launch_artificial_viscosity(P, st);
-        launch_recalculate_viscosity(P, st);
-        launch_stress(P, st);
-        launch_viscous_update(P, st);
-        if (P.adiabatic)
-            launch_substep3(P, 1, st);
-        apply_boundary(c, false);
-        Dev Q = P;
-        Q.src_ring_nparts = 0;
-        marched = launch_transport(Q, P, st);
     }
-    c->P.cfl_ring_nparts = 0; // (partial ring sums from the marching kernels: disabled)
+    Q.src_ring_nparts = 0;
+    apply_boundary_view(c, Q, false);
+    if (frog)
+        launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step (saved in cfl_dt)
+    const int marched = launch_transport(Q, P, st);
+    c->P.cfl_ring_nparts = 0;
     if (!marched)
         launch_clock_advance(P.clk, st);
+    if (frog) {
+        launch_clock_scale_dt(P.clk, 2, 0.0, 0.5, st); // dt <- step/2
+        enqueue_potential(c, true);
+        c->pressure_valid = false; // compute_pressure(data), simulation.cpp:378
+        if (P.adiabatic)
+            ensure_pressure(c);
+        if (enqueue_kick(c)) { // result in the *_b buffers: bring it home
+            const size_t ns = (size_t)P.nr * P.nphi * sizeof(double), nv = (size_t)(P.nr + 1) * P.nphi * sizeof(double);
+            (void)hipMemcpyAsync(P.vrad, P.vrad_b, nv, hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(P.vazi, P.vazi_b, ns, hipMemcpyDeviceToDevice, st);
+        }
+        launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step, for the damping of the final boundary call
+    }
     c->stepped = true;
 }
 
@@ -256,10 +305,6 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     }
     if (!d->body_force_from_potential) {
         set_error("BodyForceFromPotential: no is not supported");
-        return FCPT_EINVAL;
-    }
-    if (d->integrator != FCPT_INTEGRATOR_EULER) {
-        set_error("Integrator: Leapfrog is not supported yet");
         return FCPT_EINVAL;
     }
     if ((long long)(d->nr_global + 1) * (long long)d->nphi >= (1ll << 31)) {
@@ -496,7 +541,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
             fcpt_destroy(c);
             return rc;
         }
-        P.damp_in_step = (d->damping && any && !mean) ? 1 : 0;
+        // leapfrog kicks the gas once more after the transport, so its damping cannot be folded in
+        P.damp_in_step = (d->damping && any && !mean && d->integrator == FCPT_INTEGRATOR_EULER) ? 1 : 0;
         if (const char *e = getenv("FCPT_FUSED_DAMPING"))
             if (e[0] == '0')
                 P.damp_in_step = 0;
@@ -653,6 +699,24 @@ int fcpt_set_bodies(fcpt_ctx *c, int32_t n, const double *x, const double *y, co
     P.indirect_x = ix;
     P.indirect_y = iy;
     c->potential_valid = false;
+    c->has_mid = false;
+    return FCPT_OK;
+}
+
+int fcpt_set_bodies_midstep(fcpt_ctx *c, int32_t n, const double *x, const double *y, const double *m,
+                            const double *rsm)
+{
+    if (!c || n != c->P.nbodies || (n > 0 && (!x || !y || !m))) {
+        set_error("fcpt_set_bodies_midstep must follow fcpt_set_bodies with the same number of bodies");
+        return FCPT_EINVAL;
+    }
+    for (int k = 0; k < n; ++k) {
+        c->mx[k] = x[k];
+        c->my[k] = y[k];
+        c->mm[k] = m[k];
+        c->mrsm[k] = rsm ? rsm[k] : 0.0;
+    }
+    c->has_mid = true;
     return FCPT_OK;
 }
 
@@ -733,7 +797,7 @@ int fcpt_step_device(fcpt_ctx *c)
     if (!c)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    enqueue_step(c);
+    enqueue_step(c, true, 0.0);
     HIPCHK(hipGetLastError());
     return FCPT_OK;
 }
@@ -783,8 +847,7 @@ int fcpt_step(fcpt_ctx *c, double dt)
     if (!c)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    launch_clock_set_dt(c->P.clk, dt, c->stream);
-    enqueue_step(c);
+    enqueue_step(c, false, dt);
     HIPCHK(hipGetLastError());
     return FCPT_OK;
 }
@@ -909,7 +972,7 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
         // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
         for (; n < nsteps; ++n) {
             launch_cfl(c->P, 1, c->P.cfl_ring_nparts > 0, c->stream); // CFL + CalculateTimeStep policy on the device
-            enqueue_step(c);
+            enqueue_step(c, true, 0.0);
             enqueue_post(c);
         }
         HIPCHK(hipGetLastError());

@@ -53,6 +53,7 @@ void launch_pressure(const Dev &P, hipStream_t st);
 void launch_temperature(const Dev &P, hipStream_t st);
 void launch_cfl(const Dev &P, int apply_policy, int use_part, hipStream_t st);
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st);
+void launch_clock_scale_dt(DevClock *clk, int mode, double dt, double factor, hipStream_t st);
 void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st);
 void launch_clock_policy_ptr(DevClock *clk, double cfl_max_var, const double *cfl_global, hipStream_t st);
 void launch_clock_advance(DevClock *clk, hipStream_t st);

@@ -1904,6 +1904,16 @@ __global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *p
 // ---------------------------------------------------------------------------
 // clock kernels (single thread)
 __global__ void k_clock_set_dt(DevClock *clk, double dt) { clk->dt = dt; }
+// leapfrog sub-steps: mode 0: step <- dt (host value), mode 1: step <- clk->dt (device value),
+// mode 2: step <- the saved one; then clk->dt = factor * step.  The full step is parked in cfl_dt.
+__global__ void k_clock_scale_dt(DevClock *clk, int mode, double dt, double factor)
+{
+    if (mode == 0)
+        clk->cfl_dt = dt;
+    else if (mode == 1)
+        clk->cfl_dt = clk->dt;
+    clk->dt = mode == 2 && factor == 1.0 ? clk->cfl_dt : clk->cfl_dt * factor;
+}
 __global__ void k_clock_advance(DevClock *clk)
 {
     clk->time += clk->dt;
@@ -2258,6 +2268,10 @@ void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st)
 void launch_clock_policy_ptr(DevClock *clk, double cfl_max_var, const double *cfl_global, hipStream_t st)
 {
     KLAUNCH(KID_CLOCK, k_clock_policy_ptr, dim3(1), dim3(1), clk, cfl_max_var, cfl_global);
+}
+void launch_clock_scale_dt(DevClock *clk, int mode, double dt, double factor, hipStream_t st)
+{
+    KLAUNCH(KID_CLOCK, k_clock_scale_dt, dim3(1), dim3(1), clk, mode, dt, factor);
 }
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st)
 {

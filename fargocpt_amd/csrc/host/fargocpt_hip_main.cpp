@@ -1,0 +1,543 @@
+// fargocpt_hip -- host driver over the C ABI: reads a FargoCPT YAML setup, runs the gas update
+// on the GPU with the reference's main loop and writes snapshots in the reference's format.
+//
+//   fargocpt_hip [-q] [-N <steps>] start <config.yml>
+//
+// Counterpart of src/main.cpp:47-164 + sim::run (src/simulation.cpp:505-558) +
+// handle_outputs (:50-98) for the gas path only.  N-body objects do not feel anything here
+// (no REBOUND, no disk feedback): the star sits at the origin and every planet moves on its
+// initial circular orbit, seen in the frame rotating with OmegaFrame.
+//
+// Supported configuration keys: the ones the hot path consumes (SURVEY.md section 5 "Config /
+// flags"); unit suffixes au / solMass / jupiterMass / earthMass / g/cm2 / K are understood
+// for the default unit system (l0 = 1 au, m0 = 1 solMass).  Unknown keys are ignored with a
+// warning unless -q (the reference treats them as fatal: src/config.cpp:134-138).
+#include "../../../include/fargocpt_hip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+namespace {
+
+std::string lower(std::string s)
+{
+    std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+    return s;
+}
+std::string trim(const std::string &s)
+{
+    const size_t a = s.find_first_not_of(" \t\r\n");
+    if (a == std::string::npos)
+        return "";
+    const size_t b = s.find_last_not_of(" \t\r\n");
+    return s.substr(a, b - a + 1);
+}
+std::string unquote(std::string v)
+{
+    v = trim(v);
+    if (v.size() >= 2 && (v.front() == '\'' || v.front() == '"') && v.back() == v.front())
+        v = v.substr(1, v.size() - 2);
+    return v;
+}
+
+// "key: value  # comment" lines and one list of maps ("nbody:"), which is all the reference's
+// setups use (src/config.cpp wraps yaml-cpp; keys are case-insensitive, :344-349).
+struct Config {
+    std::map<std::string, std::string> kv;
+    std::vector<std::map<std::string, std::string>> nbody;
+    mutable std::map<std::string, bool> used;
+
+    bool load(const std::string &path)
+    {
+        std::ifstream f(path);
+        if (!f)
+            return false;
+        std::string line;
+        bool in_nbody = false;
+        while (std::getline(f, line)) {
+            // strip comments (a '#' preceded by whitespace or at column 0)
+            for (size_t i = 0; i < line.size(); ++i)
+                if (line[i] == '#' && (i == 0 || line[i - 1] == ' ' || line[i - 1] == '\t')) {
+                    line = line.substr(0, i);
+                    break;
+                }
+            if (trim(line).empty())
+                continue;
+            const bool indented = line[0] == ' ' || line[0] == '\t' || line[0] == '-';
+            std::string t = trim(line);
+            if (in_nbody && indented) {
+                if (t[0] == '-') {
+                    nbody.emplace_back();
+                    t = trim(t.substr(1));
+                }
+                const size_t c = t.find(':');
+                if (c != std::string::npos && !nbody.empty())
+                    nbody.back()[lower(trim(t.substr(0, c)))] = unquote(t.substr(c + 1));
+                continue;
+            }
+            in_nbody = false;
+            const size_t c = t.find(':');
+            if (c == std::string::npos)
+                continue;
+            const std::string key = lower(trim(t.substr(0, c)));
+            const std::string val = unquote(t.substr(c + 1));
+            if (key == "nbody") {
+                in_nbody = true;
+                continue;
+            }
+            kv[key] = val;
+        }
+        return true;
+    }
+    bool has(const std::string &k) const { return kv.count(lower(k)) > 0; }
+    std::string str(const std::string &k, const std::string &def) const
+    {
+        used[lower(k)] = true;
+        auto it = kv.find(lower(k));
+        return it == kv.end() ? def : it->second;
+    }
+    bool flag(const std::string &k, bool def) const
+    {
+        const std::string v = lower(str(k, def ? "yes" : "no"));
+        return !v.empty() && (v[0] == 'y' || v[0] == 't' || v[0] == '1');
+    }
+};
+
+// code units of the default unit system (src/units.cpp:158-185)
+const double G_CGS = 6.67430e-8, KB = 1.380649e-16, MU = 1.66053906660e-24;
+const double L0 = 1.495978707e13, M0 = 1.988409870698051e33;
+const double TEMP0 = G_CGS * MU / KB * M0 / L0;
+
+// "<number> [unit]" -> code units for the quantity kind
+enum Kind { K_NONE, K_LEN, K_MASS, K_SIGMA, K_TEMP };
+double number(const std::string &s, Kind kind)
+{
+    std::istringstream is(s);
+    double v = 0;
+    std::string u;
+    is >> v;
+    is >> u;
+    u = lower(u);
+    if (u.empty())
+        return v;
+    if (kind == K_LEN) {
+        if (u == "au")
+            return v;
+        if (u == "cm")
+            return v / L0;
+        if (u == "solradius")
+            return v * 6.957e10 / L0;
+    } else if (kind == K_MASS) {
+        if (u == "solmass")
+            return v;
+        if (u == "jupitermass")
+            return v * 9.547919e-4;
+        if (u == "earthmass")
+            return v * 3.0034893e-6;
+    } else if (kind == K_SIGMA) {
+        if (u == "g/cm2")
+            return v / (M0 / (L0 * L0));
+    } else if (kind == K_TEMP) {
+        if (u == "k")
+            return v / TEMP0;
+    }
+    fprintf(stderr, "fargocpt_hip: unit '%s' in '%s' not understood\n", u.c_str(), s.c_str());
+    exit(2);
+}
+double num(const Config &c, const std::string &k, double def, Kind kind = K_NONE)
+{
+    if (!c.has(k)) {
+        c.used[lower(k)] = true;
+        return def;
+    }
+    return number(c.str(k, ""), kind);
+}
+
+int bc_of(const std::string &s)
+{
+    const std::string v = lower(s);
+    if (v == "zerogradient") return FCPT_BC_ZEROGRADIENT;
+    if (v == "reference") return FCPT_BC_REFERENCE;
+    if (v == "reflecting") return FCPT_BC_REFLECTING;
+    if (v == "outflow") return FCPT_BC_OUTFLOW;
+    if (v == "keplerian") return FCPT_BC_KEPLERIAN;
+    if (v == "zeroshear") return FCPT_BC_ZEROSHEAR;
+    if (v == "none") return FCPT_BC_NONE;
+    fprintf(stderr, "fargocpt_hip: boundary condition '%s' is not supported\n", s.c_str());
+    exit(2);
+}
+int damp_of(const std::string &s) // damping.cpp:152-178
+{
+    switch (s.empty() ? 'n' : std::tolower(s[0])) {
+    case 'r': case 'i': case 'y': return FCPT_DAMP_REFERENCE;
+    case 'm': return FCPT_DAMP_MEAN;
+    case 'z': return FCPT_DAMP_ZERO;
+    default: return FCPT_DAMP_NONE;
+    }
+}
+
+// parameters::read + Interpret (src/parameters.cpp:520-900, src/Interpret.cpp:73-700) for the
+// keys of the path
+void config_to_desc(const Config &c, fcpt_desc &d)
+{
+    fcpt_desc_default(&d);
+    d.nr_global = (int)num(c, "Nrad", 64);
+    d.nphi = (int)num(c, "Naz", 64);
+    d.rmin = num(c, "Rmin", d.rmin, K_LEN);
+    d.rmax = num(c, "Rmax", d.rmax, K_LEN);
+    switch (std::tolower(c.str("RadialSpacing", "Arithmetic")[0])) {
+    case 'l': d.radial_spacing = FCPT_SPACING_LOGARITHMIC; break;
+    case 'e': d.radial_spacing = FCPT_SPACING_EXPONENTIAL; break;
+    default: d.radial_spacing = FCPT_SPACING_ARITHMETIC;
+    }
+    d.exponential_cell_size_factor = num(c, "ExponentialCellSizeFactor", 1.41);
+    const std::string eos = lower(c.str("EquationOfState", "Isothermal"));
+    d.eos = (eos == "ideal" || eos == "adiabatic") ? FCPT_EOS_IDEAL : FCPT_EOS_ISOTHERMAL;
+    d.adiabatic_index = num(c, "AdiabaticIndex", 7.0 / 5.0);
+    if (d.eos == FCPT_EOS_IDEAL && d.adiabatic_index == 1.0)
+        d.eos = FCPT_EOS_ISOTHERMAL; // Interpret.cpp:425-431
+    d.mu = num(c, "mu", 1.0);
+    d.aspect_ratio = num(c, "AspectRatio", 0.05);
+    d.flaring_index = num(c, "FlaringIndex", 0.0);
+    d.minimum_temperature = num(c, "MinimumTemperature", 3.0 / TEMP0, K_TEMP);
+    d.maximum_temperature = num(c, "MaximumTemperature", 1.0e300 / TEMP0, K_TEMP);
+    d.sigma0 = num(c, "Sigma0", 173.0 / (M0 / (L0 * L0)), K_SIGMA);
+    d.sigma_slope = num(c, "SigmaSlope", 0.0);
+    d.sigma_floor = num(c, "SigmaFloor", 1e-9);
+    d.set_sigma0 = c.flag("SetSigma0", false);
+    d.disk_mass = num(c, "DiskMass", 0.01, K_MASS);
+    d.viscous_alpha = num(c, "ViscousAlpha", 0.0);
+    d.constant_viscosity = num(c, "ConstantViscosity", 0.0);
+    d.radial_viscosity_factor = num(c, "RadialViscosityFactor", 1.0);
+    d.stabilize_viscosity = (int)num(c, "StabilizeViscosity", 0);
+    switch (std::tolower(c.str("ArtificialViscosity", "SN")[0])) {
+    case 'n': d.artificial_viscosity = FCPT_ARTVISC_NONE; break;
+    case 't': d.artificial_viscosity = FCPT_ARTVISC_TW; break;
+    default: d.artificial_viscosity = FCPT_ARTVISC_SN;
+    }
+    d.artificial_viscosity_dissipation = c.flag("ArtificialViscosityDissipation", true);
+    d.artificial_viscosity_factor = num(c, "ArtificialViscosityFactor", 1.41);
+    d.heating_viscous = c.flag("HeatingViscous", true);
+    d.heating_viscous_factor = num(c, "HeatingViscousFactor", 1.0);
+    d.fast_transport = std::tolower(c.str("Transport", "Fast")[0]) == 'f';
+    const std::string lim = lower(c.str("FluxLimiter", "VanLeer"));
+    d.flux_limiter = (lim == "mc" || lim == "m") ? FCPT_LIMITER_MC : FCPT_LIMITER_VANLEER;
+    d.integrator = std::tolower(c.str("Integrator", "Euler")[0]) == 'l' ? FCPT_INTEGRATOR_LEAPFROG : FCPT_INTEGRATOR_EULER;
+    d.cfl = num(c, "CFL", 0.5);
+    d.cfl_max_var = num(c, "CFLmaxVar", 1.1);
+    d.first_dt = num(c, "FirstDT", 1e-9);
+    d.heating_cooling_cfl_limit = num(c, "HeatingCoolingCFLlimit", 10.0);
+    d.monitor_timestep = num(c, "MonitorTimestep", 1.0);
+    d.nmonitor = (int)num(c, "Nmonitor", 10);
+    d.nsnapshots = (int)num(c, "Nsnapshots", 1000);
+    d.omega_frame = num(c, "OmegaFrame", 0.0);
+    d.thickness_smoothing = num(c, "ThicknessSmoothing", 0.6);
+    d.body_force_from_potential = c.flag("BodyForceFromPotential", true);
+    d.initialize_vradial_zero = c.flag("InitializeVradialZero", false);
+    d.initialize_pure_keplerian = c.flag("InitializePureKeplerian", false);
+    if ((int)num(c, "ShockTube", 0) == 1) {
+        d.ic = FCPT_IC_SHOCKTUBE;
+        d.G = d.Rgas = 1.0; // init_shock_tube_test, src/init.cpp:507-512
+    } else if (c.flag("SpreadingRing", false)) {
+        d.ic = FCPT_IC_SPREADING_RING;
+    }
+    // boundary_conditions/config.cpp:345-440 composites, :97-343 per-variable overrides
+    const char *side[2] = {"Inner", "Outer"};
+    for (int s = 0; s < 2; ++s) {
+        const std::string comp = lower(c.str(std::string(side[s]) + "Boundary", "individual"));
+        std::string sig = "zerogradient", en = "zerogradient", vr = "zerogradient";
+        if (comp == "outflow") vr = "outflow";
+        else if (comp == "reflecting") vr = "reflecting";
+        else if (comp == "reference") sig = en = vr = "reference";
+        else if (comp != "zerogradient" && comp != "individual") {
+            fprintf(stderr, "fargocpt_hip: %sBoundary: %s is not supported\n", side[s], comp.c_str());
+            exit(2);
+        }
+        d.bc_sigma[s] = bc_of(c.str(std::string(side[s]) + "BoundarySigma", sig));
+        d.bc_energy[s] = bc_of(c.str(std::string(side[s]) + "BoundaryEnergy", en));
+        d.bc_vrad[s] = bc_of(c.str(std::string(side[s]) + "BoundaryVrad", vr));
+        d.bc_vaz[s] = bc_of(c.str(std::string(side[s]) + "BoundaryVazi", "keplerian"));
+        d.keplerian_vaz_factor[s] = num(c, std::string(side[s]) + "BoundaryVaziKeplerianFactor", 1.0);
+        d.keplerian_vrad_factor[s] = num(c, std::string(side[s]) + "BoundaryVradKeplerianFactor", 0.1);
+        d.damp_vrad[s] = damp_of(c.str(std::string("DampingVRadial") + side[s], "None"));
+        d.damp_vaz[s] = damp_of(c.str(std::string("DampingVAzimuthal") + side[s], "None"));
+        d.damp_sigma[s] = damp_of(c.str(std::string("DampingSurfaceDensity") + side[s], "None"));
+        d.damp_energy[s] = damp_of(c.str(std::string("DampingEnergy") + side[s], "None"));
+    }
+    d.damping = c.flag("Damping", false);
+    d.damping_inner_limit = num(c, "DampingInnerLimit", 1.05);
+    d.damping_outer_limit = num(c, "DampingOuterLimit", 0.95);
+    d.damping_time_factor = num(c, "DampingTimeFactor", 1.0);
+    d.damping_time_radius_outer = num(c, "DampingTimeRadiusOuter", d.rmax, K_LEN);
+    // hydro centre = the first body (HydroFrameCenter: primary)
+    if (!c.nbody.empty() && c.nbody[0].count("mass"))
+        d.hydro_center_mass = number(c.nbody[0].at("mass"), K_MASS);
+}
+
+struct Body {
+    double a, m, phase, rsm_factor;
+};
+
+void mkdirs(const std::string &p)
+{
+    std::string acc;
+    for (size_t i = 0; i < p.size(); ++i) {
+        acc += p[i];
+        if (p[i] == '/' || i + 1 == p.size())
+            mkdir(acc.c_str(), 0755);
+    }
+}
+
+#define CHECK(call)                                                                      \
+    do {                                                                                 \
+        const int rc_ = (call);                                                          \
+        if (rc_ != FCPT_OK) {                                                            \
+            fprintf(stderr, "fargocpt_hip: %s failed (%d): %s\n", #call, rc_, fcpt_last_error()); \
+            exit(1);                                                                     \
+        }                                                                                \
+    } while (0)
+
+// write2D (src/polargrid.cpp:135-180): raw FP64, global row-major, single slab => whole grid
+void write_grid(fcpt_ctx *ctx, int field, size_t n, const std::string &path)
+{
+    std::vector<double> buf(n);
+    CHECK(fcpt_download(ctx, field, buf.data()));
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f || fwrite(buf.data(), sizeof(double), n, f) != n) {
+        fprintf(stderr, "fargocpt_hip: cannot write %s\n", path.c_str());
+        exit(1);
+    }
+    fclose(f);
+}
+
+struct misc_entry { // src/output.h:16-24
+    unsigned int timestep;
+    unsigned int nTimeStep;
+    double time;
+    double OmegaFrame;
+    double FrameAngle;
+    double last_dt;
+    unsigned long int N_iter;
+};
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    bool quiet = false;
+    long max_steps = -1;
+    std::string mode, cfgpath;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-q")
+            quiet = true;
+        else if (a == "-N" && i + 1 < argc)
+            max_steps = atol(argv[++i]);
+        else if (mode.empty())
+            mode = a;
+        else
+            cfgpath = a;
+    }
+    if (mode != "start" || cfgpath.empty()) {
+        fprintf(stderr, "usage: fargocpt_hip [-q] [-N steps] start <config.yml>\n");
+        return 2;
+    }
+    Config cfg;
+    if (!cfg.load(cfgpath)) {
+        fprintf(stderr, "Can not find config file %s!\n", cfgpath.c_str());
+        return 1;
+    }
+    fcpt_desc d;
+    config_to_desc(cfg, d);
+    std::string outdir = cfg.str("OutputDir", "output/out");
+    if (outdir.back() != '/')
+        outdir += "/";
+    // keys the path does not consume are tolerated here (the reference dies on unknown keys)
+    if (!quiet)
+        for (auto &kv : cfg.kv)
+            if (!cfg.used.count(kv.first) && kv.first.compare(0, 5, "write") != 0 &&
+                kv.first.compare(0, 8, "particle") != 0)
+                fprintf(stderr, "fargocpt_hip: note: key '%s' is not used by the gas path\n", kv.first.c_str());
+
+    // bodies: star + planets on fixed circular orbits
+    std::vector<Body> bodies;
+    for (size_t k = 0; k < cfg.nbody.size(); ++k) {
+        const auto &b = cfg.nbody[k];
+        Body o;
+        o.a = b.count("semi-major axis") ? number(b.at("semi-major axis"), K_LEN) : 0.0;
+        o.m = b.count("mass") ? number(b.at("mass"), K_MASS) : 0.0;
+        o.phase = 0.0;
+        o.rsm_factor = b.count("cubic smoothing factor") ? number(b.at("cubic smoothing factor"), K_NONE) : 0.0;
+        bodies.push_back(o);
+    }
+    if (bodies.empty())
+        bodies.push_back({0.0, d.hydro_center_mass, 0.0, 0.0});
+
+    std::vector<double> radii(d.nr_global + FCPT_GEOM_PAD + 1);
+    CHECK(fcpt_radii(&d, radii.data()));
+    const size_t ns = (size_t)d.nr_global * d.nphi, nv = (size_t)(d.nr_global + 1) * d.nphi;
+    std::vector<double> sigma(ns), vrad(nv), vazi(ns), energy(ns);
+    CHECK(fcpt_initial_fields(&d, radii.data(), sigma.data(), vrad.data(), vazi.data(), energy.data()));
+    fcpt_ctx *ctx = nullptr;
+    CHECK(fcpt_create(&d, radii.data(), &ctx));
+    CHECK(fcpt_upload(ctx, FCPT_F_SIGMA, sigma.data()));
+    CHECK(fcpt_upload(ctx, FCPT_F_VRAD, vrad.data()));
+    CHECK(fcpt_upload(ctx, FCPT_F_VAZI, vazi.data()));
+    CHECK(fcpt_upload(ctx, FCPT_F_ENERGY, energy.data()));
+
+    auto set_bodies = [&](double t) {
+        double x[FCPT_MAX_BODIES], y[FCPT_MAX_BODIES], m[FCPT_MAX_BODIES], rsm[FCPT_MAX_BODIES];
+        const int n = (int)std::min<size_t>(bodies.size(), FCPT_MAX_BODIES);
+        for (int k = 0; k < n; ++k) {
+            const Body &b = bodies[k];
+            const double om = b.a > 0 ? std::sqrt(d.G * (d.hydro_center_mass + b.m) / (b.a * b.a * b.a)) : 0.0;
+            const double ang = b.phase + (om - d.omega_frame) * t;
+            x[k] = b.a * std::cos(ang);
+            y[k] = b.a * std::sin(ang);
+            m[k] = b.m;
+            // dimensionless Roche radius ~ (q/3)^(1/3) (Theo.cpp:251-277 converges to it for small q)
+            rsm[k] = b.a * std::cbrt(b.m / (3.0 * d.hydro_center_mass)) * b.rsm_factor;
+        }
+        CHECK(fcpt_set_bodies(ctx, n, x, y, m, rsm, 0.0, 0.0));
+    };
+    set_bodies(0.0);
+    CHECK(fcpt_init_physics(ctx));
+
+    // ---- output files -------------------------------------------------------------------------
+    mkdirs(outdir + "snapshots/");
+    mkdirs(outdir + "monitor/");
+    {
+        FILE *f = fopen((outdir + "used_rad.dat").c_str(), "w"); // src/init.cpp:228-246
+        for (int n = 0; n <= d.nr_global; ++n)
+            fprintf(f, "%.18g\n", radii[n]);
+        fclose(f);
+        f = fopen((outdir + "dimensions.dat").c_str(), "w"); // src/parameters.cpp:1127-1176
+        const char *sp[] = {"Arithmetic", "Logarithmic", "Exponential"};
+        fprintf(f, "#RMIN\tRMAX\tPHIMIN\tPHIMAX          \tNRAD\tNAZ\tNGHRAD\tNGHAZ\tRadial_spacing\n");
+        fprintf(f, "%.16g\t%.16g\t%.16g\t%.16g\t%d\t%d\t%d\t%d\t%s\n", d.rmin, d.rmax, 0.0, 2 * M_PI, d.nr_global, d.nphi, 1,
+                1, sp[d.radial_spacing]);
+        fclose(f);
+        remove((outdir + "snapshots/list.txt").c_str());
+    }
+    auto write_snapshot = [&](unsigned nsnap, unsigned nmon) {
+        fcpt_clock clk;
+        CHECK(fcpt_get_clock(ctx, &clk));
+        const std::string dir = outdir + "snapshots/" + std::to_string(nsnap) + "/";
+        mkdirs(dir);
+        write_grid(ctx, FCPT_F_SIGMA, ns, dir + "Sigma.dat");
+        write_grid(ctx, FCPT_F_VRAD, nv, dir + "vrad.dat");
+        write_grid(ctx, FCPT_F_VAZI, ns, dir + "vazi.dat");
+        if (d.eos == FCPT_EOS_IDEAL) {
+            write_grid(ctx, FCPT_F_ENERGY, ns, dir + "energy.dat");
+            write_grid(ctx, FCPT_F_TEMPERATURE, ns, dir + "Temperature.dat");
+        }
+        misc_entry misc;
+        memset(&misc, 0, sizeof(misc));
+        misc.timestep = nsnap;
+        misc.nTimeStep = nmon;
+        misc.time = clk.time;
+        misc.OmegaFrame = d.omega_frame;
+        misc.last_dt = clk.last_dt;
+        misc.N_iter = clk.n_hydro_iter;
+        FILE *f = fopen((dir + "misc.bin").c_str(), "wb"); // src/output.cpp:494-527
+        fwrite(&misc, sizeof(misc), 1, f);
+        fclose(f);
+        std::ifstream src(cfgpath, std::ios::binary);
+        std::ofstream dst(dir + "config.yml", std::ios::binary);
+        dst << src.rdbuf();
+        f = fopen((outdir + "snapshots/list.txt").c_str(), "a");
+        fprintf(f, "%u\n", nsnap);
+        fclose(f);
+        f = fopen((outdir + "snapshots/timeSnapshot.dat").c_str(), nsnap == 0 ? "w" : "a");
+        if (nsnap == 0)
+            fprintf(f, "# Time log for course output.\n#version: 0.1\n#variable: 0 | snapshot number | 1\n"
+                       "#variable: 1 | monitor number | 1\n#variable: 2 | time | code\n");
+        fprintf(f, "%u\t%u\t%#.16e\n", nsnap, nmon, clk.time);
+        fclose(f);
+        if (!quiet)
+            printf("Writing output %s, Snapshot Number %u, Time %f.\n", dir.c_str(), nsnap, clk.time);
+    };
+
+    // ---- main.cpp:117-152 and sim::run (simulation.cpp:505-558) --------------------------------
+    auto calc_dt = [&]() {
+        double cfl, dt;
+        CHECK(fcpt_cfl(ctx, &cfl));
+        CHECK(fcpt_calculate_timestep(ctx, cfl, &dt));
+        return dt;
+    };
+    calc_dt();          // main.cpp:117
+    write_snapshot(0, 0); // main.cpp:150-152
+    CHECK(fcpt_apply_boundary(ctx, 0.0, 0)); // sim::init
+    calc_dt();
+
+    const double t_final = (double)d.nsnapshots * d.nmonitor * d.monitor_timestep;
+    FILE *tlog = fopen((outdir + "monitor/timestepLogging.dat").c_str(), "w");
+    fprintf(tlog, "#version: 2\n#FargoCPT Time log for the hydro timestep size.\n"
+                  "#variable: 0  | snapshot number | 1\n#variable: 1  | monitor number | 1\n"
+                  "#variable: 2  | hydrostep number | 1\n#variable: 3  | Number of Hydrosteps in last monitor_timestep | 1\n"
+                  "#variable: 4  | time | code\n#variable: 5  | walltime | s\n#variable: 6  | walltime per hydrostep | ms\n"
+                  "#variable: 7  | mean dt | code\n#variable: 8  | min dt | code\n#variable: 9  | max dt | code\n");
+    unsigned n_monitor = 0;
+    unsigned long n_iter = 0, n_iter_last = 0;
+    double time = 0.0, sum_dt = 0, min_dt = 1e300, max_dt = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto t_last = t_start;
+    const bool moving = bodies.size() > 1;
+    while (time < t_final) {
+        if (max_steps >= 0 && (long)n_iter >= max_steps)
+            break;
+        const double cfl_dt = calc_dt();
+        double step_dt;
+        CHECK(fcpt_snap_to_monitor(ctx, cfl_dt, &step_dt));
+        const double time_next_monitor = (n_monitor + 1) * d.monitor_timestep;
+        if (moving)
+            set_bodies(time);
+        CHECK(fcpt_step(ctx, step_dt));
+        CHECK(fcpt_post(ctx, step_dt));
+        time += step_dt;
+        ++n_iter;
+        sum_dt += step_dt;
+        min_dt = std::min(min_dt, step_dt);
+        max_dt = std::max(max_dt, step_dt);
+        if (std::fabs(time_next_monitor - time) < 1e-6 * cfl_dt) {
+            ++n_monitor;
+            fcpt_clock clk;
+            CHECK(fcpt_get_clock(ctx, &clk));
+            clk.n_monitor = n_monitor;
+            clk.n_snapshot = n_monitor / (unsigned)d.nmonitor;
+            CHECK(fcpt_set_clock(ctx, &clk));
+            const auto now = std::chrono::steady_clock::now();
+            const double wall = std::chrono::duration<double>(now - t_start).count();
+            const unsigned long nint = n_iter - n_iter_last;
+            const double ms = nint ? 1e3 * std::chrono::duration<double>(now - t_last).count() / nint : 0.0;
+            fprintf(tlog, "%u\t%u\t%lu\t%lu\t%#.16e\t%#.16e\t%#.16e\t%#.16e\t%#.16e\t%#.16e\n", clk.n_snapshot, n_monitor,
+                    n_iter, nint, time, wall, ms, nint ? sum_dt / nint : 0.0, min_dt, max_dt);
+            fflush(tlog);
+            t_last = now;
+            n_iter_last = n_iter;
+            sum_dt = 0;
+            min_dt = 1e300;
+            max_dt = 0;
+            if (n_monitor % (unsigned)d.nmonitor == 0) // handle_outputs, simulation.cpp:50-66
+                write_snapshot(n_monitor / (unsigned)d.nmonitor, n_monitor);
+        }
+    }
+    fclose(tlog);
+    CHECK(fcpt_synchronize(ctx));
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (!quiet)
+        printf("-- Final: Total Hydrosteps %lu, Time %.2f, Walltime %.2f seconds, Time per Step: %.2f milliseconds\n", n_iter,
+               time, wall, n_iter ? 1e3 * wall / n_iter : 0.0);
+    fcpt_destroy(ctx);
+    return 0;
+}

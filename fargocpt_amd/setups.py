@@ -56,8 +56,9 @@ def spreading_ring(lib: B.Library, nr=256, nphi=2) -> B.Desc:
     return d
 
 
-def shocktube(lib: B.Library, nr=100, nphi=2, artvisc="SN") -> B.Desc:
-    """test/shockTube/setups/shocktube_{SN,TW}.yml (Euler integrator variants)."""
+def shocktube(lib: B.Library, nr=100, nphi=2, artvisc="SN", leapfrog=False) -> B.Desc:
+    """test/shockTube/setups/shocktube_{SN,SN_LF,TW,TW_LF}.yml (the reference's TW setups are
+    both leapfrog; shocktube_SN.yml is the Euler one)."""
     d = lib.desc_default()
     d.nr_global, d.nphi = nr, nphi
     d.rmin, d.rmax, d.radial_spacing = 1000.0, 1001.0, B.SPACING_ARITHMETIC
@@ -82,6 +83,7 @@ def shocktube(lib: B.Library, nr=100, nphi=2, artvisc="SN") -> B.Desc:
     d.nsnapshots, d.nmonitor, d.monitor_timestep = 1, 1, 0.228
     d.G = d.Rgas = 1.0
     d.damping_time_radius_outer = d.rmax
+    d.integrator = B.INTEGRATOR_LEAPFROG if leapfrog else B.INTEGRATOR_EULER
     return d
 
 

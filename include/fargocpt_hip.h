@@ -270,6 +270,12 @@ int fcpt_device_ptr(fcpt_ctx *ctx, int32_t field, void **dptr, uint64_t *count);
 int fcpt_set_bodies(fcpt_ctx *ctx, int32_t n, const double *x, const double *y, const double *mass,
                     const double *cubic_smoothing_radius, double indirect_x, double indirect_y);
 
+/* Leapfrog only: the bodies at the mid-step time, used for the potential of the second gas
+ * kick (src/simulation.cpp:359-366).  Without this call the second kick reuses the positions of
+ * fcpt_set_bodies.  Must follow fcpt_set_bodies (same n). */
+int fcpt_set_bodies_midstep(fcpt_ctx *ctx, int32_t n, const double *x, const double *y, const double *mass,
+                            const double *cubic_smoothing_radius);
+
 /* After the initial Sigma/v/energy upload: init_euler (src/SourceEuler.cpp:251-285:
  * sound speed, pressure, temperature, scale height, viscosity), the first
  * potential, copy_initial_values + apply_boundary_condition + copy_initial_values
@@ -301,11 +307,13 @@ int fcpt_calculate_timestep(fcpt_ctx *ctx, double cfl_dt_global, double *dt);
 /* The monitor-time snapping of sim::run (src/simulation.cpp:528-540). */
 int fcpt_snap_to_monitor(const fcpt_ctx *ctx, double cfl_dt, double *step_dt);
 
-/* step_Euler up to and including Transport (src/simulation.cpp:167-217):
+/* The gas part of one step.  Integrator: Euler -- step_Euler up to and including Transport (src/simulation.cpp:167-217):
  * potential, update_with_sourceterms, update_with_artificial_viscosity,
  * recalculate_viscosity, compute_viscous_stress_tensor,
  * update_velocities_with_viscosity, SubStep3, apply_boundary_condition(final=false),
- * Transport.  Asynchronous on the context's stream.  Advances time by dt. */
+ * Transport.  Integrator: Leapfrog -- step_LeapFrog (src/simulation.cpp:316-393): gas kick 1/2 with
+ * dt/2, boundary (final=false), Transport with dt, potential at mid-step, compute_pressure,
+ * gas kick 2/2 with dt/2.  Asynchronous on the context's stream.  Advances time by dt. */
 int fcpt_step(fcpt_ctx *ctx, double dt);
 
 /* CommunicateBoundaries, device side (src/commbound.cpp:108-125,163-180):

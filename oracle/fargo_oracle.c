@@ -63,6 +63,9 @@ struct orc_ctx {
     int nbodies;
     double bx[FCPT_MAX_BODIES], by[FCPT_MAX_BODIES], bm[FCPT_MAX_BODIES], brsm[FCPT_MAX_BODIES];
     double indirect_x, indirect_y;
+    /* bodies at the mid-step time of a leapfrog step (simulation.cpp:363-366) */
+    int has_mid;
+    double mx[FCPT_MAX_BODIES], my[FCPT_MAX_BODIES], mm[FCPT_MAX_BODIES], mrsm[FCPT_MAX_BODIES];
 
     fcpt_clock clk;
 };
@@ -750,6 +753,7 @@ int orc_set_bodies(orc_ctx *c, int32_t n, const double *x, const double *y, cons
     }
     c->indirect_x = ix;
     c->indirect_y = iy;
+    c->has_mid = 0;
     return FCPT_OK;
 }
 
@@ -1949,12 +1953,9 @@ int orc_init_physics(orc_ctx *c)
     return FCPT_OK;
 }
 
-/* simulation.cpp:167-217: potential .. Transport of step_Euler */
-int orc_step(orc_ctx *c, double dt)
+/* the gas "kick" shared by both integrators (simulation.cpp:190-203 / :324-337 / :379-392) */
+static void gas_kick(orc_ctx *c, double dt)
 {
-    if (!c)
-        return FCPT_EINVAL;
-    calculate_potential(c);
     /* update_with_sourceterms, SourceEuler.cpp:435-452 */
     momentum_update_radial(c, dt);
     momentum_update_azimuthal(c, dt);
@@ -1965,10 +1966,57 @@ int orc_step(orc_ctx *c, double dt)
     update_velocities_with_viscosity(c, dt);
     if (c->d.eos == FCPT_EOS_IDEAL)
         substep3(c, dt);
-    apply_boundary_condition(c, 0.0, 0);
-    Transport(c, dt);
+}
+
+/* simulation.cpp:167-217 (step_Euler: potential .. Transport) and :316-393 (step_LeapFrog:
+ * kick 1/2, drift 1/1, kick 2/2), gas part */
+int orc_step(orc_ctx *c, double dt)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    if (c->d.integrator == FCPT_INTEGRATOR_LEAPFROG) {
+        const double frog_dt = dt / 2;
+        calculate_potential(c);
+        gas_kick(c, frog_dt);
+        apply_boundary_condition(c, 0.0, 0);
+        Transport(c, dt);
+        if (c->has_mid) { /* bodies at x_{i+1/2} */
+            double sx[FCPT_MAX_BODIES], sy[FCPT_MAX_BODIES], sm[FCPT_MAX_BODIES], sr[FCPT_MAX_BODIES];
+            memcpy(sx, c->bx, sizeof sx); memcpy(sy, c->by, sizeof sy);
+            memcpy(sm, c->bm, sizeof sm); memcpy(sr, c->brsm, sizeof sr);
+            memcpy(c->bx, c->mx, sizeof sx); memcpy(c->by, c->my, sizeof sy);
+            memcpy(c->bm, c->mm, sizeof sm); memcpy(c->brsm, c->mrsm, sizeof sr);
+            calculate_potential(c);
+            memcpy(c->bx, sx, sizeof sx); memcpy(c->by, sy, sizeof sy);
+            memcpy(c->bm, sm, sizeof sm); memcpy(c->brsm, sr, sizeof sr);
+        } else {
+            calculate_potential(c);
+        }
+        compute_pressure(c);
+        gas_kick(c, frog_dt);
+    } else {
+        calculate_potential(c);
+        gas_kick(c, dt);
+        apply_boundary_condition(c, 0.0, 0);
+        Transport(c, dt);
+    }
     c->clk.time += dt;
     c->clk.n_hydro_iter += 1;
+    return FCPT_OK;
+}
+
+int orc_set_bodies_midstep(orc_ctx *c, int32_t n, const double *x, const double *y, const double *m,
+                           const double *rsm)
+{
+    if (!c || n != c->nbodies)
+        return FCPT_EINVAL;
+    for (int k = 0; k < n; ++k) {
+        c->mx[k] = x[k];
+        c->my[k] = y[k];
+        c->mm[k] = m[k];
+        c->mrsm[k] = rsm ? rsm[k] : 0.0;
+    }
+    c->has_mid = 1;
     return FCPT_OK;
 }
 

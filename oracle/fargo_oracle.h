@@ -34,6 +34,8 @@ int orc_upload(orc_ctx *c, int32_t field, const double *host);
 int orc_download(orc_ctx *c, int32_t field, double *host);
 int orc_set_bodies(orc_ctx *c, int32_t n, const double *x, const double *y, const double *mass,
                    const double *rsm, double indirect_x, double indirect_y);
+int orc_set_bodies_midstep(orc_ctx *c, int32_t n, const double *x, const double *y, const double *mass,
+                           const double *rsm);
 int orc_init_physics(orc_ctx *c);
 int orc_cfl(orc_ctx *c, double *dt_local);
 int orc_calculate_timestep(orc_ctx *c, double cfl_dt_global, double *dt);

@@ -24,14 +24,14 @@ def main():
     lib = fargocpt_amd.load()
     orc = B.Library(ctypes.CDLL(os.path.join(ROOT, "oracle", "libfargo_oracle.so")), "orc_")
     out = {}
-    for av in ("SN", "TW"):
-        d = setups.shocktube(lib, 100, 2, av)
+    for av, lf in (("SN", False), ("TW", False), ("SN", True), ("TW", True)):
+        d = setups.shocktube(lib, 100, 2, av, leapfrog=lf)
         ctx = driver.make_context(orc, d)
         s = driver.SlabSet([ctx])
         s.prepare()
         n = ctx.run_steps(100000, snap=True)
         st = ctx.state()
-        out[f"shocktube_{av}"] = {
+        out[f"shocktube_{av}" + ("_LF" if lf else "")] = {
             "steps": n, "time": ctx.clock.time, "deviations": shocktube_deviations(lib, d, ctx),
             "sum_sigma": float(st["sigma"].sum()), "sum_energy": float(st["energy"].sum()),
             "max_vrad": float(np.abs(st["vrad"]).max())}

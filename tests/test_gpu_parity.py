@@ -145,3 +145,16 @@ def test_weak_scaling_grid_four_slabs(product, oracle):
     d.damping_time_radius_outer = d.rmax
     _check(run_pair(product, oracle, d, 15, nslabs=(n, 1), bodies=setups.jupiter_bodies(d)),
            ("sigma", "vrad", "vazi"))
+
+
+@pytest.mark.parametrize("adiabatic,nphi", [(False, 256), (True, 96), (False, 64)])
+def test_leapfrog_integrator(product, oracle, adiabatic, nphi):
+    """step_LeapFrog (src/simulation.cpp:276-459): kick 1/2, drift, kick 2/2 with the mid-step
+    bodies; isothermal (marching source kernel and the narrow-grid fused path) and adiabatic."""
+    d = setups.planet_disk(product, 48, nphi, adiabatic=adiabatic)
+    d.integrator = B.INTEGRATOR_LEAPFROG
+    fields = ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ())
+    _check(run_pair(product, oracle, d, 25, bodies=setups.jupiter_bodies(d)), fields)
+    d = setups.shocktube(product, 512, 4, "TW", leapfrog=True)
+    d.first_dt = 1e-6
+    _check(run_pair(product, oracle, d, 40, amp=0.0), ("sigma", "vrad", "vazi", "energy"))

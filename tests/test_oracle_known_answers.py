@@ -28,18 +28,23 @@ def _run_to_snapshot(lib, d):
     return ctx, n
 
 
-@pytest.mark.parametrize("av,steps", [("SN", 270), ("TW", 286)])
-def test_shocktube_analytic(product, oracle, av, steps):
-    d = setups.shocktube(product, 100, 2, av)
+@pytest.mark.parametrize("av,lf", [("SN", False), ("TW", False), ("SN", True), ("TW", True)])
+def test_shocktube_analytic(product, oracle, av, lf):
+    """SN Euler = shocktube_SN.yml, SN/TW leapfrog = shocktube_SN_LF.yml / shocktube_TW(_LF).yml
+    (step_LeapFrog, src/simulation.cpp:276-459); TW Euler is an extra combination."""
+    d = setups.shocktube(product, 100, 2, av, leapfrog=lf)
     ctx, n = _run_to_snapshot(oracle, d)
-    assert n == steps
+    key = f"shocktube_{av}" + ("_LF" if lf else "")
+    assert n == GOLD[key]["steps"]
+    if (av, lf) == ("SN", False):
+        assert n == 270  # the reference's own step count
     assert abs(ctx.clock.time - 0.228) < 1e-12
     dev = shocktube_deviations(product, d, ctx)
     for k, thr in SHOCKTUBE_THRESHOLDS.items():
         assert dev[k] < thr, (k, dev[k], thr)
-        assert dev[k] == pytest.approx(GOLD[f"shocktube_{av}"]["deviations"][k], rel=1e-9)
+        assert dev[k] == pytest.approx(GOLD[key]["deviations"][k], rel=1e-9)
     st = ctx.state()
-    assert float(st["sigma"].sum()) == pytest.approx(GOLD[f"shocktube_{av}"]["sum_sigma"], rel=1e-12)
+    assert float(st["sigma"].sum()) == pytest.approx(GOLD[key]["sum_sigma"], rel=1e-12)
 
 
 def test_spreading_ring_analytic(product, oracle):
