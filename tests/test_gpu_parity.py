@@ -158,3 +158,38 @@ def test_leapfrog_integrator(product, oracle, adiabatic, nphi):
     d = setups.shocktube(product, 512, 4, "TW", leapfrog=True)
     d.first_dt = 1e-6
     _check(run_pair(product, oracle, d, 40, amp=0.0), ("sigma", "vrad", "vazi", "energy"))
+
+
+@pytest.mark.parametrize("case", ["outflow_zeroshear", "reference_bc", "keplerian_vrad", "damp_zero", "damp_mean",
+                                  "exponential_grid", "arithmetic_grid", "odd_nphi", "no_damping_tiny"])
+def test_boundary_damping_grid_variants(product, oracle, case):
+    """Per-variable boundary conditions (src/boundary_conditions/*.cpp), damping targets
+    (damping.cpp:311-700), the three grid spacings (init.cpp:92-145) and ragged sizes."""
+    d = setups.planet_disk(product, 40, 144)
+    if case == "outflow_zeroshear":
+        for s in (0, 1):
+            d.bc_vrad[s], d.bc_vaz[s] = B.BC_OUTFLOW, B.BC_ZEROSHEAR
+    elif case == "reference_bc":
+        for s in (0, 1):
+            d.bc_sigma[s] = d.bc_energy[s] = d.bc_vrad[s] = d.bc_vaz[s] = B.BC_REFERENCE
+    elif case == "keplerian_vrad":
+        for s in (0, 1):
+            d.bc_vrad[s], d.bc_vaz[s] = B.BC_KEPLERIAN, B.BC_ZEROGRADIENT
+    elif case == "damp_zero":
+        for arr in (d.damp_vrad, d.damp_sigma):
+            arr[0] = arr[1] = B.DAMP_ZERO
+    elif case == "damp_mean":
+        for arr in (d.damp_vrad, d.damp_vaz, d.damp_sigma):
+            arr[0] = arr[1] = B.DAMP_MEAN
+    elif case == "exponential_grid":
+        d.radial_spacing = B.SPACING_EXPONENTIAL
+    elif case == "arithmetic_grid":
+        d.radial_spacing = B.SPACING_ARITHMETIC
+    elif case == "odd_nphi":
+        d.nr_global, d.nphi = 37, 131
+    elif case == "no_damping_tiny":
+        d.nr_global, d.nphi, d.damping = 16, 8, 0
+    _check(run_pair(product, oracle, d, 20, bodies=setups.jupiter_bodies(d)), ("sigma", "vrad", "vazi"))
+    da = d.copy()
+    da.eos = B.EOS_IDEAL
+    _check(run_pair(product, oracle, da, 12), ("sigma", "vrad", "vazi", "energy"))
