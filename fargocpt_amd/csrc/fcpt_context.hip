@@ -377,6 +377,17 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         if (!rc) rc = dev_upload(c, &P.g_inv_drmed2.p, c2);
         if (!rc) rc = dev_upload(c, &P.g_inv_dra2.p, d2);
         if (!rc) rc = dev_upload(c, &P.g_inv_rmsum.p, e2);
+        std::vector<double> t1(nr + 1, 0.0), t2(nr + 1, 0.0), t3(nr + 1, 0.0), t4(nr + 1, 0.0);
+        for (int i = 0; i < nr; ++i) {
+            t1[i] = g.dphi * g.Rmed[i];
+            t2[i] = 1.0 / t1[i];
+            t3[i] = (g.Rsup[i] - g.Rinf[i]) * g.InvSurf[i];
+            t4[i] = g.Rmed[i] * d->omega_frame;
+        }
+        if (!rc) rc = dev_upload(c, &P.g_dxtheta.p, t1);
+        if (!rc) rc = dev_upload(c, &P.g_inv_dxtheta.p, t2);
+        if (!rc) rc = dev_upload(c, &P.g_dr_invsurf.p, t3);
+        if (!rc) rc = dev_upload(c, &P.g_r_omega.p, t4);
     }
     {
         // isothermal alpha viscosity per ring, exactly as k_iso_cs_h + k_viscosity evaluate it:

@@ -86,6 +86,8 @@ struct Dev {
     //   g_inv_dxt_src = 2/(dphi (Rsup+Rinf)), g_inv_rsum = 1/(Rsup+Rinf), g_inv_drmed2 = 1/(Rmed[i]^2-Rmed[i-1]^2),
     //   g_inv_dra2 = 1/(Rinf[i+1]^2-Rinf[i]^2), g_inv_rmsum = 1/(Rmed[i]+Rmed[i-1])
     CArr g_inv_dxt_src, g_inv_rsum, g_inv_drmed2, g_inv_dra2, g_inv_rmsum;
+    //   g_dxtheta = dphi Rmed, g_inv_dxtheta = 1/(dphi Rmed), g_dr_invsurf = (Rsup-Rinf) InvSurf, g_r_omega = Rmed OmegaFrame
+    CArr g_dxtheta, g_inv_dxtheta, g_dr_invsurf, g_r_omega;
     // state
     double *sigma, *vrad, *vazi, *energy;
     double *vrad_b, *vazi_b; // intermediate velocities of the fused source step

@@ -69,6 +69,19 @@ __device__ __forceinline__ double fast_rcp1(double d)
 __device__ __forceinline__ double dmin(double a, double b) { return b < a ? b : a; } // std::min
 __device__ __forceinline__ double dmax(double a, double b) { return a < b ? b : a; } // std::max
 
+// Whole-wavefront shifts by one lane as DPP moves (gfx9 wave_shr:1 / wave_shl:1): the value of
+// lane-1 / lane+1, lanes 0 / 63 keep their own value.  Two VALU moves instead of two
+// ds_bpermute round trips through the LDS crossbar (profiles/tools/dpp_shift.hip).
+template <int CTRL> __device__ __forceinline__ double dpp_shift(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_prev(double x) { return dpp_shift<0x138>(x); }
+__device__ __forceinline__ double lane_next(double x) { return dpp_shift<0x130>(x); }
+
 // ---------------------------------------------------------------------------
 // Pframeforce.cpp:21-94 CalculateNbodyPotential (+ Force.cpp:124-159 smoothing)
 template <bool ROWU> __global__ void k_potential(const Dev P)
@@ -694,8 +707,8 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
     const double OmF = P.omega_frame;
     const double C2 = P.art_visc_factor * P.art_visc_factor;
 
-#define NEXT(x) __shfl_down((x), 1, 64) /* value of cell j+1 */
-#define PREV(x) __shfl_up((x), 1, 64)   /* value of cell j-1 */
+#define NEXT(x) lane_next(x) /* value of cell j+1 */
+#define PREV(x) lane_prev(x) /* value of cell j-1 */
     auto crow = [nr](int r) { return r < 0 ? 0 : (r > nr - 1 ? nr - 1 : r); };   // cell rows
     auto vrow = [nr](int r) { return r < 0 ? 0 : (r > nr ? nr : r); };           // v_r rows
     auto nu_of = [&](int r) { return P.alpha_viscosity ? P.nu_ring[crow(r)] : P.nu_const; };
@@ -1571,12 +1584,134 @@ template <bool DAMP, bool ROWU> __global__ void k_velocities(const Dev P, ThetaS
 // Validity: 4 cells at either end of a segment are lost to the two passes, one more on the
 // left to the L+(j-1) neighbour.
 #define THETA_ROWS 8
-#define THETA_LO 5
+#define THETA_LO 6 /* even, so that a lane's two cells are both final or both halo */
 #define THETA_HI 4
-template <int C, bool ADI, bool DAMP>
-__global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const double *va_pre, const double *vr_pre, ThetaSet in,
-                                                              int tiles, int periodic, int rows, int advance_clock)
+
+// two adjacent doubles moved as one 16-byte access (the address is only 8-byte aligned)
+typedef double D2v __attribute__((ext_vector_type(2)));
+typedef D2v __attribute__((aligned(8))) D2;
+#ifdef EXP_NT
+#define LD2(p_) __builtin_nontemporal_load((const D2 *)(p_))
+#define ST2(p_, v_) __builtin_nontemporal_store((v_), (D2 *)(p_))
+#else
+#define LD2(p_) (*(const D2 *)(p_))
+#define ST2(p_, v_) (*(D2 *)(p_) = (v_))
+#endif
+
+// 0.5 * flux_limiter(a, b) (TransportEuler.cpp:306-337): the factor 2 of van Leer's 2ab/(a+b)
+// and the 0.5 of the half-cell slope cancel exactly.
+__device__ __forceinline__ double half_limiter(int type, double a, double b)
 {
+    if (type == FCPT_LIMITER_MC)
+        return 0.5 * limiter(type, a, b);
+    const double ab = a * b;
+    return ab > 0.0 ? ab * fast_rcp1(a + b) : 0.0;
+}
+
+// Upwind star states of one quantity on the C cells of a lane (compute_star_theta,
+// TransportEuler.cpp:408-441): st = q_upwind + (dist / dxtheta) * half_limited_difference_upwind.
+// MODE 0: per-cell upwind direction up[c] and distance factor d2[c]; MODE 1 / 2: the whole ring
+// moves with one velocity > 0 / <= 0 (second FARGO pass), so the upwind choice is made at compile
+// time and the selects disappear.
+template <int C, bool PER, int MODE>
+__device__ __forceinline__ void theta_star(int lim, int lsrc_l, int lsrc_r, const double (&W)[C], const bool (&up)[C],
+                                           const double (&d2)[C], double d2u, double (&st)[C])
+{
+#define SH_PREV(x) (PER ? __shfl((x), lsrc_l, 64) : lane_prev(x))
+#define SH_NEXT(x) (PER ? __shfl((x), lsrc_r, 64) : lane_next(x))
+    const double wl = SH_PREV(W[C - 1]); // cell -1
+    const double wr = SH_NEXT(W[0]);     // cell C
+    double h[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double wm = c == 0 ? wl : W[c == 0 ? 0 : c - 1];
+        const double wp = c == C - 1 ? wr : W[c == C - 1 ? C - 1 : c + 1];
+        h[c] = half_limiter(lim, wp - W[c], W[c] - wm);
+    }
+    if (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            st[c] = W[c] + d2u * h[c];
+        return;
+    }
+    const double hl = SH_PREV(h[C - 1]); // slope of cell -1
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double wm = c == 0 ? wl : W[c == 0 ? 0 : c - 1];
+        const double hm = c == 0 ? hl : h[c == 0 ? 0 : c - 1];
+        if (MODE == 1)
+            st[c] = wm + d2u * hm;
+        else
+            st[c] = (up[c] ? wm : W[c]) + d2[c] * (up[c] ? hm : h[c]);
+    }
+}
+
+// One azimuthal pass (OneWindTheta's VanLeerTheta calls, TransportEuler.cpp:443-496,583-628) on
+// the cells of a lane.  geo_dt = (Rsup-Rinf) * InvSurf * dt; V the per-cell velocity (MODE 0) or vu
+// the ring velocity (MODE 1/2).  The interface mass flux F = geo_dt * v * rho* is formed once and
+// shared by all quantities: Q += q*(c) F(c) - q*(c+1) F(c+1).
+template <int C, bool ADI, bool PER, int MODE>
+__device__ __forceinline__ void theta_pass(int lim, int lsrc_l, int lsrc_r, double geo_dt, double dxtheta, double invdx,
+                                           double dt, const double (&V)[C], double vu, double (&S)[C], double (&Q)[4][C],
+                                           double (&E)[C])
+{
+    bool up[C];
+    double d2[C], d2u = 0.0;
+    if (MODE == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double ksi = V[c] * dt;
+            up[c] = ksi > 0.0;
+            d2[c] = (up[c] ? (dxtheta - ksi) : -(dxtheta + ksi)) * invdx;
+        }
+    } else {
+        const double ksi = vu * dt;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            up[c] = MODE == 1;
+            d2[c] = 0.0;
+        }
+        d2u = (MODE == 1 ? (dxtheta - ksi) : -(dxtheta + ksi)) * invdx;
+    }
+    double rho[C], F[C + 1], rS[C];
+    theta_star<C, PER, MODE>(lim, lsrc_l, lsrc_r, S, up, d2, d2u, rho);
+    const double gvu = geo_dt * vu;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        F[c] = (MODE == 0 ? geo_dt * V[c] : gvu) * rho[c];
+        rS[c] = fast_rcp(S[c]);
+    }
+    F[C] = SH_NEXT(F[0]);
+    auto advect = [&](double (&X)[C]) {
+        double Wq[C], qs[C], fl[C + 1];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            Wq[c] = X[c] * rS[c];
+        theta_star<C, PER, MODE>(lim, lsrc_l, lsrc_r, Wq, up, d2, d2u, qs);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            fl[c] = qs[c] * F[c];
+        fl[C] = SH_NEXT(fl[0]);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            X[c] += fl[c] - fl[c + 1];
+    };
+    advect(Q[0]);
+    advect(Q[1]);
+    advect(Q[2]);
+    advect(Q[3]);
+    if (ADI)
+        advect(E);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        S[c] += F[c] - F[c + 1];
+}
+
+template <int C, bool ADI, bool DAMP, bool PER>
+__global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const double *va_pre, const double *vr_pre, ThetaSet in,
+                                                              int tiles, int rows, int advance_clock)
+{
+    constexpr int periodic = PER ? 1 : 0;
     // va_pre / vr_pre: the pre-transport (post-source, post-boundary) velocities; the new state goes to P's grids
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -1602,6 +1737,7 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
         lsrc_r = lsrc_r > 63 ? 63 : lsrc_r;
     }
     const double dt = P.clk->dt;
+    const int lim = P.limiter;
     auto wrap = [nphi](int j) { return j < 0 ? j + nphi : (j >= nphi ? j - nphi : j); };
 
     int jout[C];
@@ -1612,145 +1748,92 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
         jout[c] = wrap(a + ln * C + c);
         valid[c] = act && (periodic || (pos >= THETA_LO && pos < 64 * C - THETA_HI && a + pos < nphi));
     }
+    // 16-byte stores when, for every lane, the two cells are adjacent in memory and final together
+    const bool pair_out =
+        C == 2 && !PER && __builtin_amdgcn_ballot_w64(jout[C - 1] != jout[0] + 1 || valid[0] != valid[C - 1]) == 0;
     double rmp_prev[C], S_prev[C]; // transported rm+ and Sigma of ring i-1 at the same output cells
 #pragma unroll
     for (int c = 0; c < C; ++c)
         rmp_prev[c] = S_prev[c] = 0.0;
 
-#define THETA_FLUX(st, W_)                                                                          \
-    {                                                                                               \
-        const double wl = __shfl(W_[C - 1], lsrc_l, 64); /* cell -1 */                              \
-        const double wr = __shfl(W_[0], lsrc_r, 64);     /* cell C  */                              \
-        double dq[C];                                                                               \
-        _Pragma("unroll") for (int c = 0; c < C; ++c)                                               \
-        {                                                                                           \
-            const double wm = c == 0 ? wl : W_[c == 0 ? 0 : c - 1];                                \
-            const double wp = c == C - 1 ? wr : W_[c == C - 1 ? C - 1 : c + 1];                     \
-            dq[c] = 0.5 * limiter(P.limiter, wp - W_[c], W_[c] - wm) * invdxtheta;                  \
-        }                                                                                           \
-        const double dql = __shfl(dq[C - 1], lsrc_l, 64); /* slope of cell -1 */                    \
-        _Pragma("unroll") for (int c = 0; c < C; ++c)                                               \
-        {                                                                                           \
-            const double xa = up[c] ? (c == 0 ? wl : W_[c == 0 ? 0 : c - 1]) : W_[c];               \
-            const double sl = up[c] ? (c == 0 ? dql : dq[c == 0 ? 0 : c - 1]) : dq[c];              \
-            st[c] = xa + dist[c] * sl;                                                              \
-        }                                                                                           \
-    }
-
-    struct RingIn {
-        double s, rmp, rmm, lp, lm, e, va;
-    };
-    auto ring_load = [&](int ii, RingIn *r) {
-        const int rrow = ii * nphi;
-        int ns = P.nshift_c[ii] % nphi;
-        ns = ns < 0 ? ns + nphi : ns;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int g = rrow + wrap(jout[c] - ns); // the cell that AdvectSHIFT moves onto jout
-            r[c].s = in.sig[g];
-            r[c].rmp = in.rmp[g];
-            r[c].rmm = in.rmm[g];
-            r[c].lp = in.lp[g];
-            r[c].lm = in.lm[g];
-            r[c].e = ADI ? in.e[g] : 0.0;
-            r[c].va = va_pre[g];
-        }
-    };
     const int i0 = r0 > 0 ? r0 - 1 : 0;
     for (int i = i0; i < r1; ++i) {
-        RingIn nxt[C];
-        ring_load(i, nxt);
         const int row = i * nphi;
         const double mean = P.vmean_c[i];
         const double vconst = P.vconst_c[i];
         const double vadd = P.fast_transport ? 0.0 : vconst;
         double S[C], Q[4][C], E[C], V[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            S[c] = nxt[c].s;
-            Q[0][c] = nxt[c].rmp;
-            Q[1][c] = nxt[c].rmm;
-            Q[2][c] = nxt[c].lp;
-            Q[3][c] = nxt[c].lm;
-            E[c] = nxt[c].e;
-            V[c] = vadd + (nxt[c].va - mean);
-        }
-        const double dxtheta = P.dphi * P.Rmed[i];
-        const double invdxtheta = 1.0 / dxtheta;
-        const double dxrad = (P.Rsup[i] - P.Rinf[i]) * dt;
-        const double invsurf = P.InvSurf[i];
-        for (int pass = 1; pass <= 2; ++pass) {
-            if (pass == 2) {
-                if (!P.fast_transport)
-                    break;
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    V[c] = vconst;
-            }
-            bool up[C];
-            double dist[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const double ksi = V[c] * dt;
-                up[c] = ksi > 0.0;
-                dist[c] = up[c] ? (dxtheta - ksi) : -(dxtheta + ksi);
-            }
-            double rho[C], rS[C];
-            THETA_FLUX(rho, S);
+        {
+            int ns = P.nshift_c[i] % nphi;
+            ns = ns < 0 ? ns + nphi : ns;
+            int gin[C];
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                rS[c] = fast_rcp(S[c]);
-#define THETA_Q(X)                                                                                  \
-            {                                                                                       \
-                double Wq[C], fl[C + 1], qs[C];                                                     \
-                _Pragma("unroll") for (int c = 0; c < C; ++c) Wq[c] = X[c] * rS[c];                 \
-                THETA_FLUX(qs, Wq);                                                                 \
-                _Pragma("unroll") for (int c = 0; c < C; ++c) fl[c] = dxrad * qs[c] * rho[c] * V[c]; \
-                fl[C] = __shfl(fl[0], lsrc_r, 64);                                                  \
-                _Pragma("unroll") for (int c = 0; c < C; ++c)                                       \
-                {                                                                                   \
-                    double varq = fl[c];                                                            \
-                    varq -= fl[c + 1];                                                              \
-                    X[c] += varq * invsurf;                                                         \
-                }                                                                                   \
-            }
-            THETA_Q(Q[0]);
-            THETA_Q(Q[1]);
-            THETA_Q(Q[2]);
-            THETA_Q(Q[3]);
-            if (ADI)
-                THETA_Q(E);
-            {
-                double fl[C + 1];
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    fl[c] = dxrad * 1.0 * rho[c] * V[c];
-                fl[C] = __shfl(fl[0], lsrc_r, 64);
+                gin[c] = row + wrap(jout[c] - ns); // the cell that AdvectSHIFT moves onto jout
+            // 2 cells per lane: one 16-byte load per grid unless the ring seam falls inside a lane's pair
+            const bool pairs = C == 2 && !PER && __builtin_amdgcn_ballot_w64(gin[C - 1] != gin[0] + 1) == 0;
+            if (pairs) {
+                const D2 s2 = LD2(in.sig + gin[0]), a2 = LD2(in.rmp + gin[0]), b2 = LD2(in.rmm + gin[0]);
+                const D2 c2 = LD2(in.lp + gin[0]), d2 = LD2(in.lm + gin[0]), v2 = LD2(va_pre + gin[0]);
+                D2 e2 = {0.0, 0.0};
+                if (ADI)
+                    e2 = LD2(in.e + gin[0]);
+                S[0] = s2.x, S[C - 1] = s2.y;
+                Q[0][0] = a2.x, Q[0][C - 1] = a2.y;
+                Q[1][0] = b2.x, Q[1][C - 1] = b2.y;
+                Q[2][0] = c2.x, Q[2][C - 1] = c2.y;
+                Q[3][0] = d2.x, Q[3][C - 1] = d2.y;
+                E[0] = e2.x, E[C - 1] = e2.y;
+                V[0] = vadd + (v2.x - mean), V[C - 1] = vadd + (v2.y - mean);
+            } else {
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    double varq = fl[c];
-                    varq -= fl[c + 1];
-                    S[c] += varq * invsurf;
+                    const int g = gin[c];
+                    S[c] = in.sig[g];
+                    Q[0][c] = in.rmp[g];
+                    Q[1][c] = in.rmm[g];
+                    Q[2][c] = in.lp[g];
+                    Q[3][c] = in.lm[g];
+                    E[c] = ADI ? in.e[g] : 0.0;
+                    V[c] = vadd + (va_pre[g] - mean);
                 }
             }
-#undef THETA_Q
         }
+        const double dxtheta = P.g_dxtheta[i];
+        const double invdx = P.g_inv_dxtheta[i];
+        const double geo_dt = P.g_dr_invsurf[i] * dt;
+#ifndef EXP_THETA_NOCOMP
+        theta_pass<C, ADI, PER, 0>(lim, lsrc_l, lsrc_r, geo_dt, dxtheta, invdx, dt, V, 0.0, S, Q, E);
+#else
+#pragma unroll
+        for (int c = 0; c < C; ++c) { Q[1][c] += Q[0][c] * 1e-9; Q[3][c] += (Q[2][c] + V[c]) * 1e-9; }
+#endif
+#ifndef EXP_THETA_NOCOMP
+        if (P.fast_transport) {
+            if (vconst * dt > 0.0)
+                theta_pass<C, ADI, PER, 1>(lim, lsrc_l, lsrc_r, geo_dt, dxtheta, invdx, dt, V, vconst, S, Q, E);
+            else
+                theta_pass<C, ADI, PER, 2>(lim, lsrc_l, lsrc_r, geo_dt, dxtheta, invdx, dt, V, vconst, S, Q, E);
+        }
+#endif
         // compute_velocities_from_momenta + floors + damping for ring i (rings < r0 only prime rmp/S)
         if (i >= r0) {
-            const double lp_l = __shfl(Q[2][C - 1], lsrc_l, 64); // L+ and Sigma of cell j-1
-            const double s_l = __shfl(S[C - 1], lsrc_l, 64);
+            const double lp_l = SH_PREV(Q[2][C - 1]); // L+ and Sigma of cell j-1
+            const double s_l = SH_PREV(S[C - 1]);
             const double fs = DAMP ? P.dfac_s[i] : 0.0, ts = DAMP ? P.dtau_s[i] : 1.0;
             const int tvr = DAMP ? P.dtype_vr[i] : 0, tva = DAMP ? P.dtype_va[i] : 0;
             const int tsg = DAMP ? P.dtype_sig[i] : 0, ten = DAMP ? P.dtype_e[i] : 0;
             const double fv = DAMP ? P.dfac_v[i] : 0.0, tv = DAMP ? P.dtau_v[i] : 1.0;
+            const double invr = P.InvRmed[i], romega = P.g_r_omega[i];
+            double o_vr[C], o_va[C], o_s[C], o_e[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const double lpm = c == 0 ? lp_l : Q[2][c == 0 ? 0 : c - 1];
                 const double sm = c == 0 ? s_l : S[c == 0 ? 0 : c - 1];
                 double vr = 0.0;
                 if (i != 0)
-                    vr = (rmp_prev[c] + Q[1][c]) / (S_prev[c] + S[c]);
-                double va = (lpm + Q[3][c]) / (sm + S[c]) * P.InvRmed[i] - P.Rmed[i] * P.omega_frame;
+                    vr = (rmp_prev[c] + Q[1][c]) * fast_rcp(S_prev[c] + S[c]);
+                double va = (lpm + Q[3][c]) * fast_rcp(sm + S[c]) * invr - romega;
                 double sf = S[c] < P.sigma_floor_abs ? P.sigma_floor_abs : S[c];
                 double e = ADI ? clamp_energy(P, E[c], sf) : 0.0;
                 const int g = row + jout[c];
@@ -1761,20 +1844,39 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
                     if (ADI)
                         e = damp_value(P, e, ten, fs, ts, dt, P.energy0, g, 0.0);
                 }
-                if (valid[c]) {
-                    P.vrad[g] = vr;
-                    P.vazi[g] = va;
-                    P.sigma[g] = sf;
+                o_vr[c] = vr, o_va[c] = va, o_s[c] = sf, o_e[c] = e;
+            }
+            if (pair_out) { // both cells of the lane are final and adjacent in memory
+                if (valid[0]) {
+                    const int g = row + jout[0];
+                    ST2(P.vrad + g, (D2{o_vr[0], o_vr[C - 1]}));
+                    ST2(P.vazi + g, (D2{o_va[0], o_va[C - 1]}));
+                    ST2(P.sigma + g, (D2{o_s[0], o_s[C - 1]}));
                     if (ADI)
-                        P.energy[g] = e;
-                    if (i == nr - 1) { // v_r row Nr is not transported: it keeps its post-boundary value
+                        ST2(P.energy + g, (D2{o_e[0], o_e[C - 1]}));
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (valid[c]) {
+                        const int g = row + jout[c];
+                        P.vrad[g] = o_vr[c];
+                        P.vazi[g] = o_va[c];
+                        P.sigma[g] = o_s[c];
+                        if (ADI)
+                            P.energy[g] = o_e[c];
+                    }
+            }
+            if (i == nr - 1) { // v_r row Nr is not transported: it keeps its post-boundary value
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (valid[c]) {
                         double v = vr_pre[nr * nphi + jout[c]];
                         if (DAMP)
                             v = damp_value(P, v, P.dtype_vr[nr], P.dfac_v[nr], P.dtau_v[nr], dt, P.vrad0,
                                            nr * nphi + jout[c], 0.0);
                         P.vrad[nr * nphi + jout[c]] = v;
                     }
-                }
             }
         }
 #pragma unroll
@@ -1787,7 +1889,8 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
         P.clk->time += dt;
         P.clk->n_hydro_iter += 1;
     }
-#undef THETA_FLUX
+#undef SH_PREV
+#undef SH_NEXT
 }
 
 // ---------------------------------------------------------------------------
@@ -2151,9 +2254,6 @@ int launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         }
     if (!C && P.nphi > 64 * 2)
         C = 2;
-    if (const char *e = getenv("FCPT_THETA_C")) // tuning knob: cells per lane in tiled mode
-        if (!periodic && (e[0] == '1' || e[0] == '2' || e[0] == '4') && P.nphi > 64 * (e[0] - '0'))
-            C = e[0] - '0';
     if (const char *e = getenv("FCPT_THETA_FUSED"))
         if (e[0] == '0')
             C = 0;
@@ -2170,27 +2270,29 @@ int launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         const int waves = chunks * tiles;
         marched_tiles = tiles;
         const dim3 grid((waves + 3) / 4), block(256);
-#define MARCHK(CC, AA, DD) \
-    KLAUNCH(KID_THETA_MARCH, (k_transport_theta_march<CC, AA, DD>), grid, block, W, (const double *)P.vazi, (const double *)P.vrad, \
-            inB, tiles, periodic, rows, 1)
-#define MARCHC(CC)                     \
-    if (P.adiabatic) {                 \
-        if (W.damp_in_step)            \
-            MARCHK(CC, true, true);    \
-        else                           \
-            MARCHK(CC, true, false);   \
-    } else {                           \
-        if (W.damp_in_step)            \
-            MARCHK(CC, false, true);   \
-        else                           \
-            MARCHK(CC, false, false);  \
+#define MARCHK(CC, PP, AA, DD)                                                                                   \
+    KLAUNCH(KID_THETA_MARCH, (k_transport_theta_march<CC, AA, DD, PP>), grid, block, W, (const double *)P.vazi, \
+            (const double *)P.vrad, inB, tiles, rows, 1)
+#define MARCHC(CC, PP)                   \
+    if (P.adiabatic) {                   \
+        if (W.damp_in_step)              \
+            MARCHK(CC, PP, true, true);  \
+        else                             \
+            MARCHK(CC, PP, true, false); \
+    } else {                             \
+        if (W.damp_in_step)              \
+            MARCHK(CC, PP, false, true); \
+        else                             \
+            MARCHK(CC, PP, false, false);\
     }
-        if (C == 1) {
-            MARCHC(1)
+        if (!periodic) { // tiled: 2 cells per lane (1, 4 and 6 were measured slower), DPP lane shifts
+            MARCHC(2, false)
+        } else if (C == 1) {
+            MARCHC(1, true)
         } else if (C == 2) {
-            MARCHC(2)
+            MARCHC(2, true)
         } else {
-            MARCHC(4)
+            MARCHC(4, true)
         }
 #undef MARCHC
 #undef MARCHK
