@@ -45,6 +45,31 @@ static inline Launch2D launch2d(int nrows, int nphi)
 #define JNEXT (j == P.nphi - 1 ? 0 : j + 1)
 #define JPREV (j == 0 ? P.nphi - 1 : j - 1)
 
+// two adjacent doubles moved as one 16-byte access (the address is only 8-byte aligned)
+typedef double D2v __attribute__((ext_vector_type(2)));
+typedef D2v __attribute__((aligned(8))) D2;
+#ifdef EXP_NT
+#define LD2(p_) __builtin_nontemporal_load((const D2 *)(p_))
+#define ST2(p_, v_) __builtin_nontemporal_store((v_), (D2 *)(p_))
+#else
+#define LD2(p_) (*(const D2 *)(p_))
+#define ST2(p_, v_) (*(D2 *)(p_) = (v_))
+#endif
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The marching kernels
+// give every XCD a contiguous range of logical blocks, so that neighbouring phi tiles and ring
+// chunks -- which read the same halo cells -- meet in one L2 instead of fetching them twice from
+// HBM.  Bijective for any block count (blockIdx % 8 only labels blocks that share an XCD).
+__device__ __forceinline__ int xcd_block(int b, int nb)
+{
+#ifdef FCPT_NO_XCD_REMAP
+    return b;
+#else
+    const int q = nb >> 3, r = nb & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+#endif
+}
+
 // Reciprocal from v_rcp_f64 (~2^-26) refined by two Newton steps: ~1 ulp, less than half the
 // issue cost of the IEEE division sequence.  Used only where the result feeds a limited
 // slope or a specific quantity (errors of a few ulp there are far inside the 1e-10 parity bar).
@@ -692,7 +717,7 @@ template <int AV> // 0: none, 1: TW, 2: SN
 __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chunk = wave / segs;
     const int seg = wave - chunk * segs;
     const int nr = P.nr, nphi = P.nphi;
@@ -894,72 +919,75 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
 // ---------------------------------------------------------------------------
 // boundary_conditions/{zero_gradient,reference,reflecting,outflow,keplerian_*,zero_shear}.cpp
 // called in the order of boundary_conditions.cpp:65-114; one thread per phi column.
-__device__ __forceinline__ void bc_scalar(const Dev &P, double *x, const double *x0, int type,
-                                          int outer, int j)
+// All loads first, then all stores: the ghost values only depend on active rings (or on the
+// reference fields), so the ~10 memory round trips of the sequential form collapse into one.
+struct BcScalar {
+    bool on;
+    double v;
+};
+__device__ __forceinline__ BcScalar bc_scalar_load(const Dev &P, const double *x, const double *x0, int type, int outer,
+                                                   int j)
 {
     const int Irad = P.nr - 1;
-    if (!outer) {
-        if (!P.is_first)
-            return;
-        if (type == FCPT_BC_ZEROGRADIENT)
-            x[IDX(0, j)] = x[IDX(1, j)];
-        else if (type == FCPT_BC_REFERENCE)
-            x[IDX(0, j)] = x0[IDX(0, j)];
-    } else {
-        if (!P.is_last)
-            return;
-        if (type == FCPT_BC_ZEROGRADIENT)
-            x[IDX(Irad, j)] = x[IDX(Irad - 1, j)];
-        else if (type == FCPT_BC_REFERENCE)
-            x[IDX(Irad, j)] = x0[IDX(Irad, j)];
+    BcScalar r = {false, 0.0};
+    if ((!outer && !P.is_first) || (outer && !P.is_last))
+        return r;
+    if (type == FCPT_BC_ZEROGRADIENT) {
+        r.on = true;
+        r.v = x[IDX(outer ? Irad - 1 : 1, j)];
+    } else if (type == FCPT_BC_REFERENCE) {
+        r.on = true;
+        r.v = x0[IDX(outer ? Irad : 0, j)];
     }
+    return r;
 }
 __global__ void k_boundary(const Dev P)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.nphi)
         return;
-    bc_scalar(P, P.sigma, P.sigma0, P.bc_sigma[0], 0, j);
-    bc_scalar(P, P.sigma, P.sigma0, P.bc_sigma[1], 1, j);
-    bc_scalar(P, P.energy, P.energy0, P.bc_energy[0], 0, j);
-    bc_scalar(P, P.energy, P.energy0, P.bc_energy[1], 1, j);
-    double *vr = P.vrad;
-    const double *v0 = P.vrad0;
+    const int Irad = P.nr - 1;
     const int Iv = P.nr; // max_radial of the vector grid
+    // ---- loads ---------------------------------------------------------------------------
+    BcScalar sg[2], en[2];
+    for (int outer = 0; outer < 2; ++outer) {
+        sg[outer] = bc_scalar_load(P, P.sigma, P.sigma0, P.bc_sigma[outer], outer, j);
+        en[outer] = bc_scalar_load(P, P.energy, P.energy0, P.bc_energy[outer], outer, j);
+    }
+    bool vr_on[2] = {false, false}, va_on[2] = {false, false};
+    double vr_g0[2] = {0.0, 0.0}, vr_g1[2] = {0.0, 0.0}, va_g[2] = {0.0, 0.0};
     for (int outer = 0; outer < 2; ++outer) {
         const int type = P.bc_vrad[outer];
+        const int g0 = outer ? Iv : 0, g1 = outer ? Iv - 1 : 1, a = outer ? Iv - 2 : 2;
         if (type == FCPT_BC_REFLECTING) { // no rank guard in the reference (reflecting.cpp:15-40)
-            if (!outer) {
-                vr[IDX(0, j)] = -vr[IDX(2, j)];
-                vr[IDX(1, j)] = 0;
-            } else {
-                vr[IDX(Iv, j)] = -vr[IDX(Iv - 2, j)];
-                vr[IDX(Iv - 1, j)] = 0;
-            }
+            vr_on[outer] = true;
+            vr_g0[outer] = -P.vrad[IDX(a, j)];
+            vr_g1[outer] = 0.0;
             continue;
         }
         if ((!outer && !P.is_first) || (outer && !P.is_last))
             continue;
-        const int g0 = outer ? Iv : 0, g1 = outer ? Iv - 1 : 1, a = outer ? Iv - 2 : 2;
         switch (type) {
         case FCPT_BC_ZEROGRADIENT:
-            vr[IDX(g0, j)] = vr[IDX(a, j)];
-            vr[IDX(g1, j)] = vr[IDX(a, j)];
+            vr_on[outer] = true;
+            vr_g0[outer] = vr_g1[outer] = P.vrad[IDX(a, j)];
             break;
         case FCPT_BC_REFERENCE:
-            vr[IDX(g0, j)] = v0[IDX(g0, j)];
-            vr[IDX(g1, j)] = v0[IDX(g1, j)];
+            vr_on[outer] = true;
+            vr_g0[outer] = P.vrad0[IDX(g0, j)];
+            vr_g1[outer] = P.vrad0[IDX(g1, j)];
             break;
         case FCPT_BC_OUTFLOW: {
-            const double va = vr[IDX(a, j)];
+            const double va = P.vrad[IDX(a, j)];
             const bool inflow = outer ? (va < 0.0) : (va > 0.0);
-            vr[IDX(g1, j)] = inflow ? 0.0 : va;
-            vr[IDX(g0, j)] = inflow ? 0.0 : va;
+            vr_on[outer] = true;
+            vr_g0[outer] = vr_g1[outer] = inflow ? 0.0 : va;
             break;
         }
         case FCPT_BC_KEPLERIAN:
-            vr[IDX(g0, j)] = P.kep_vrad[outer] * sqrt(P.G * P.Mc / P.Rmed[g0]);
-            vr[IDX(g1, j)] = P.kep_vrad[outer] * sqrt(P.G * P.Mc / P.Rmed[g1]);
+            vr_on[outer] = true;
+            vr_g0[outer] = P.kep_vrad[outer] * sqrt(P.G * P.Mc / P.Rmed[g0]);
+            vr_g1[outer] = P.kep_vrad[outer] * sqrt(P.G * P.Mc / P.Rmed[g1]);
             break;
         default:
             break;
@@ -969,24 +997,42 @@ __global__ void k_boundary(const Dev P)
         const int type = P.bc_vaz[outer];
         if ((!outer && !P.is_first) || (outer && !P.is_last))
             continue;
-        const int row = outer ? P.nr - 1 : 0, act = outer ? P.nr - 2 : 1;
+        const int row = outer ? Irad : 0, act = outer ? Irad - 1 : 1;
         const double r = P.Rmed[row];
         switch (type) {
         case FCPT_BC_ZEROGRADIENT:
-            P.vazi[IDX(row, j)] = P.vazi[IDX(act, j)];
+            va_on[outer] = true;
+            va_g[outer] = P.vazi[IDX(act, j)];
             break;
         case FCPT_BC_REFERENCE:
-            P.vazi[IDX(row, j)] = P.vazi0[IDX(row, j)];
+            va_on[outer] = true;
+            va_g[outer] = P.vazi0[IDX(row, j)];
             break;
         case FCPT_BC_KEPLERIAN:
-            P.vazi[IDX(row, j)] = P.kep_vaz[outer] * sqrt(P.G * P.Mc / r) - r * P.omega_frame;
+            va_on[outer] = true;
+            va_g[outer] = P.kep_vaz[outer] * sqrt(P.G * P.Mc / r) - r * P.omega_frame;
             break;
         case FCPT_BC_ZEROSHEAR:
-            P.vazi[IDX(row, j)] = r * (P.vazi[IDX(act, j)] / P.Rmed[act]);
+            va_on[outer] = true;
+            va_g[outer] = r * (P.vazi[IDX(act, j)] / P.Rmed[act]);
             break;
         default:
             break;
         }
+    }
+    // ---- stores --------------------------------------------------------------------------
+    for (int outer = 0; outer < 2; ++outer) {
+        const int row = outer ? Irad : 0;
+        if (sg[outer].on)
+            P.sigma[IDX(row, j)] = sg[outer].v;
+        if (en[outer].on)
+            P.energy[IDX(row, j)] = en[outer].v;
+        if (vr_on[outer]) {
+            P.vrad[IDX(outer ? Iv : 0, j)] = vr_g0[outer];
+            P.vrad[IDX(outer ? Iv - 1 : 1, j)] = vr_g1[outer];
+        }
+        if (va_on[outer])
+            P.vazi[IDX(row, j)] = va_g[outer];
     }
 }
 
@@ -1152,8 +1198,9 @@ __device__ __forceinline__ RadialFlux radial_flux(const Dev &P, int k, double v,
 }
 template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(const Dev P)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r0_ = (blockIdx.y * blockDim.y + threadIdx.y) * RADIAL_ROWS;
+    const int lb = xcd_block(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int j = (lb % gridDim.x) * blockDim.x + threadIdx.x;
+    const int r0_ = ((lb / gridDim.x) * blockDim.y + threadIdx.y) * RADIAL_ROWS;
     if (j >= P.nphi || r0_ >= P.nr)
         return;
     const int r0 = ROWU ? __builtin_amdgcn_readfirstlane(r0_) : r0_;
@@ -1196,44 +1243,63 @@ template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(c
 }
 
 // compute_average_azimuthal_velocity (:174-189) + ComputeConstantResidual (:207-236):
-// one block per ring; wavefront shuffles + LDS for the ring sum.
-__global__ void k_ring_mean(const Dev P, int with_shift, const double *part, int nparts, int pstride)
+// one wavefront per ring (4 rings per block), 16-byte loads with 8 in flight per lane, DPP-free
+// butterfly for the ring sum; the per-ring scalars of the epilogue are fetched up front so the
+// last lane-0 instructions do not queue behind three dependent memory round trips.
+__global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, const double *part, int nparts, int pstride)
 {
     // part != nullptr: the producer kernel left nparts partial sums per ring (fixed order, so the
     // result is deterministic); rings rewritten afterwards by a boundary condition are re-summed
     // from the grid.
-    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (i >= P.nr)
+        return;
+    const double dt = with_shift ? P.clk->dt : 1.0;
+    const double invr = P.InvRmed[i], rmed = P.Rmed[i];
     const bool ghost = (i == 0 && P.is_first && P.bc_vaz[0] != FCPT_BC_NONE) ||
                        (i == P.nr - 1 && P.is_last && P.bc_vaz[1] != FCPT_BC_NONE) ||
                        (!P.is_first && i < FCPT_OVERLAP) || (!P.is_last && i >= P.nr - FCPT_OVERLAP);
     double acc = 0.0;
     if (part && !ghost) {
-        for (int n = threadIdx.x; n < nparts; n += blockDim.x)
+        for (int n = lane; n < nparts; n += 64)
             acc += part[i * pstride + n];
     } else {
-        for (int j = threadIdx.x; j < P.nphi; j += blockDim.x)
-            acc += P.vazi[IDX(i, j)];
+        const double *row = P.vazi + (size_t)i * P.nphi;
+        const int npair = P.nphi >> 1;
+        double acc2 = 0.0;
+        int n = lane;
+        for (; n + 7 * 64 < npair; n += 8 * 64) {
+            D2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = *(const D2 *)(row + 2 * (n + u * 64));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc += v[u].x;
+                acc2 += v[u].y;
+            }
+        }
+        for (; n < npair; n += 64) {
+            const D2 v = *(const D2 *)(row + 2 * n);
+            acc += v.x;
+            acc2 += v.y;
+        }
+        if ((P.nphi & 1) && lane == 0)
+            acc += row[P.nphi - 1];
+        acc += acc2;
     }
     for (int off = 32; off > 0; off >>= 1)
         acc += __shfl_down(acc, off, 64);
-    __shared__ double s_w[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0)
-        s_w[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double sum = s_w[0];
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
-            sum += s_w[w];
-        const double mean = sum / (double)P.nphi;
+    if (lane == 0) {
+        const double mean = acc / (double)P.nphi;
         P.vmean[i] = mean;
         if (with_shift) {
-            const double dt = P.clk->dt;
             const double invdt = 1.0 / dt;
-            const double Ntilde = mean * P.InvRmed[i] * dt * P.invdphi;
+            const double Ntilde = mean * invr * dt * P.invdphi;
             const double Nround = floor(Ntilde + 0.5);
             P.nshift[i] = (int)Nround;
-            P.vconst[i] = (Ntilde - Nround) * P.Rmed[i] * invdt * P.dphi;
+            P.vconst[i] = (Ntilde - Nround) * rmed * invdt * P.dphi;
         }
     }
 }
@@ -1587,17 +1653,6 @@ template <bool DAMP, bool ROWU> __global__ void k_velocities(const Dev P, ThetaS
 #define THETA_LO 6 /* even, so that a lane's two cells are both final or both halo */
 #define THETA_HI 4
 
-// two adjacent doubles moved as one 16-byte access (the address is only 8-byte aligned)
-typedef double D2v __attribute__((ext_vector_type(2)));
-typedef D2v __attribute__((aligned(8))) D2;
-#ifdef EXP_NT
-#define LD2(p_) __builtin_nontemporal_load((const D2 *)(p_))
-#define ST2(p_, v_) __builtin_nontemporal_store((v_), (D2 *)(p_))
-#else
-#define LD2(p_) (*(const D2 *)(p_))
-#define ST2(p_, v_) (*(D2 *)(p_) = (v_))
-#endif
-
 // 0.5 * flux_limiter(a, b) (TransportEuler.cpp:306-337): the factor 2 of van Leer's 2ab/(a+b)
 // and the 0.5 of the half-cell slope cancel exactly.
 __device__ __forceinline__ double half_limiter(int type, double a, double b)
@@ -1714,7 +1769,7 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
     constexpr int periodic = PER ? 1 : 0;
     // va_pre / vr_pre: the pre-transport (post-source, post-boundary) velocities; the new state goes to P's grids
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chunk = wave / tiles;
     const int r0 = chunk * rows;
     const int nr = P.nr;
@@ -1891,6 +1946,342 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
     }
 #undef SH_PREV
 #undef SH_NEXT
+}
+
+// ===========================================================================
+// The whole Transport() (TransportEuler.cpp:112-136) in ONE pass over memory.
+//
+// A wavefront owns 64*C consecutive phi columns in PRE-shift coordinates and marches outward
+// ring by ring.  Per step it loads one ring of Sigma, v_r, v_phi(, e) (the only HBM reads), and
+//   R  radial sweep: specific momenta w(m), limited half slopes of ring m-1, the upwind fluxes
+//      through interface m-1 (each evaluated once, shared mass flux), update of ring m-2
+//      (compute_momenta_from_velocities + OneWindRad, :138-167,471-493,545-620) -- all column-local,
+//      a rolling register window of three rings;
+//   T  both azimuthal passes on ring m-2 (theta_pass, as k_transport_theta_march) with phi
+//      neighbours by DPP lane shifts;
+//   V  velocities from momenta, floors, wave damping (:498-535,121-131) and the store of the new
+//      state at the POST-shift address (column + Nshift[i], AdvectSHIFT :238-268 is free).
+// v_r(i) couples rings i-1 and i at one post-shift column, i.e. at lanes that differ by
+// Nshift[i] - Nshift[i-1].  The FARGO shear limit of the CFL condition (cfl.cpp:207-220) keeps
+// that difference in {-1, 0, 1} for every admissible dt, so one lane shift of the previous ring
+// is enough; k_ring_mean raises P.shift_jump otherwise and the unfused kernels run instead.
+// Nothing intermediate reaches memory: 3 (4) grids read + 3 (4) written instead of 8 + 9
+// (10 + 11) doubles per cell for k_transport_radial + k_transport_theta_march.
+// Validity in cells of a 64*C segment: right 1 (L+ needs v_phi(j+1)), 4 at either end for the
+// two passes, left 1 for L+(j-1), 1 at either end for the v_r lane shift.
+#define TF_ROWS 16
+template <int C> struct TfHalo {
+    static constexpr int lo = C == 2 ? 6 : 5; // even for C = 2: a lane's two cells are final together
+    static constexpr int hi = 6;
+};
+
+template <int C, bool ADI, bool DAMP>
+__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows)
+{
+    // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
+    constexpr int LO = TfHalo<C>::lo, HI = TfHalo<C>::hi;
+    constexpr int NQ = ADI ? 6 : 5; // s, rmp, rmm, lp, lm(, e)
+    if (*P.shift_jump)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int chunk = wave / tiles;
+    const int r0 = chunk * rows;
+    const int nr = P.nr, nphi = P.nphi;
+    if (r0 >= nr)
+        return;
+    const int r1 = r0 + rows < nr ? r0 + rows : nr;
+    const int tile = wave - chunk * tiles;
+    const int stride = 64 * C - (LO + HI);
+    const int a = tile * stride - LO; // first pre-shift column of the segment
+    const double dt = P.clk->dt;
+    const int lim = P.limiter;
+    auto wrap = [nphi](int j) { return j < 0 ? j + nphi : (j >= nphi ? j - nphi : j); };
+
+    int jin[C];
+    bool valid[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int pos = lane * C + c;
+        jin[c] = wrap(a + pos);
+        valid[c] = pos >= LO && pos < 64 * C - HI && a + pos < nphi;
+    }
+    const bool pair_in = C == 2 && __builtin_amdgcn_ballot_w64(jin[C - 1] != jin[0] + 1) == 0;
+    const bool pair_valid = C == 2 && __builtin_amdgcn_ballot_w64(valid[0] != valid[C - 1]) == 0;
+
+    // rolling window: index 0 = ring m (newest), 1 = m-1, 2 = m-2
+    double w[3][NQ][C];  // specific quantities (w[.][0] = Sigma itself; energy: e / Sigma)
+    double er[3][C];     // the energy itself
+    double vp[3][C];     // v_phi as loaded
+    double d1[NQ][C];    // (w(m-1) - w(m-2)) InvDiffRmed[m-1]
+    double hs1[NQ][C];   // limited half slope of ring m-2
+    double F1[NQ][C];    // flux through interface m-2
+    double vr0[C], vr1[C]; // v_r(m), v_r(m-1)
+    double rmp_prev[C], S_prev[C]; // transported rm+ and Sigma of the previous ring
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            w[0][q][c] = w[1][q][c] = w[2][q][c] = d1[q][c] = hs1[q][c] = F1[q][c] = 0.0;
+        er[0][c] = er[1][c] = er[2][c] = vp[0][c] = vp[1][c] = vp[2][c] = 0.0;
+        vr0[c] = vr1[c] = rmp_prev[c] = S_prev[c] = 0.0;
+    }
+    auto load_vr = [&](int k, double (&out)[C]) {
+        if (k < 0 || k > nr) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                out[c] = 0.0;
+            return;
+        }
+        const double *row = P.vrad + (size_t)k * nphi;
+        if (pair_in) {
+            const D2 v = LD2(row + jin[0]);
+            out[0] = v.x, out[C - 1] = v.y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                out[c] = row[jin[c]];
+        }
+    };
+    load_vr(r0 - 3, vr0);
+    int ns_prev = 0;
+
+    for (int m = r0 - 3; m <= r1 + 1; ++m) {
+        // ---- rotate the window and load ring m ------------------------------------------------
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                w[2][q][c] = w[1][q][c];
+                w[1][q][c] = w[0][q][c];
+            }
+            er[2][c] = er[1][c], er[1][c] = er[0][c];
+            vp[2][c] = vp[1][c], vp[1][c] = vp[0][c];
+            vr1[c] = vr0[c];
+        }
+        double vrn[C]; // v_r(m+1)
+        load_vr(m + 1, vrn);
+        const bool in_m = m >= 0 && m < nr;
+        if (in_m) {
+            const size_t row = (size_t)m * nphi;
+            double sg[C], va[C], en[C];
+            if (pair_in) {
+                const D2 s2 = LD2(P.sigma + row + jin[0]), v2 = LD2(P.vazi + row + jin[0]);
+                D2 e2 = {0.0, 0.0};
+                if (ADI)
+                    e2 = LD2(P.energy + row + jin[0]);
+                sg[0] = s2.x, sg[C - 1] = s2.y, va[0] = v2.x, va[C - 1] = v2.y, en[0] = e2.x, en[C - 1] = e2.y;
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    sg[c] = P.sigma[row + jin[c]];
+                    va[c] = P.vazi[row + jin[c]];
+                    en[c] = ADI ? P.energy[row + jin[c]] : 0.0;
+                }
+            }
+            const double r = P.Rmed[m], romega = P.g_r_omega[m];
+            const double va_n = lane_next(va[0]); // v_phi of cell j+1 of the last cell of the lane
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double van = c == C - 1 ? va_n : va[c == C - 1 ? c : c + 1];
+                w[0][0][c] = sg[c];
+                w[0][1][c] = vrn[c];                 // rm+ / Sigma = v_r(m+1)   (:484-485)
+                w[0][2][c] = vr0[c];                 // rm- / Sigma = v_r(m)
+                w[0][3][c] = (van + romega) * r;     // L+ / Sigma = (v_phi(j+1) + r Omega) r
+                w[0][4][c] = (va[c] + romega) * r;   // L- / Sigma
+                if (ADI) {
+                    w[0][NQ - 1][c] = en[c] * fast_rcp(sg[c]);
+                    er[0][c] = en[c];
+                }
+                vp[0][c] = va[c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    w[0][q][c] = 0.0;
+                er[0][c] = vp[0][c] = 0.0;
+            }
+        }
+        // ---- R: slopes of ring m-1, fluxes through interface k = m-1 --------------------------
+        const int k = m - 1;
+        double F0[NQ][C];
+        {
+            const bool kin = m >= 1 && m <= nr - 1;          // rings m-1 and m both exist
+            const double idr_m = kin ? P.InvDiffRmed[m] : 0.0; // 1 / (Rmed[m] - Rmed[m-1])
+            const bool lim_ok = k > 0 && k < nr - 1;          // boundary rings carry no slope (:360-372)
+            const bool open = k > 0 && k < nr;                // interface carries a flux
+            const int kk = open ? k : 1;
+            const double dr_lo = P.Rmed[kk] - P.Rmed[kk - 1], dr_hi = P.Rmed[kk + 1] - P.Rmed[kk];
+            const double g = dt * P.dphi * P.Rinf[kk];
+            bool up[C];
+            double dist[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double v = vr1[c]; // v_r(m-1)
+                up[c] = v > 0.0;
+                dist[c] = up[c] ? (dr_lo - v * dt) : -(dr_hi + v * dt);
+            }
+            double Fc[C];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double d0 = (w[0][q][c] - w[1][q][c]) * idr_m;
+                    const double hs0 = lim_ok ? half_limiter(lim, d0, d1[q][c]) : 0.0; // ring m-1
+                    const double st = (up[c] ? w[2][q][c] : w[1][q][c]) + dist[c] * (up[c] ? hs1[q][c] : hs0);
+                    if (q == 0) {
+                        Fc[c] = open ? g * st * vr1[c] : 0.0; // mass flux g rho* v
+                        F0[q][c] = Fc[c];
+                    } else {
+                        F0[q][c] = st * Fc[c];
+                    }
+                    d1[q][c] = d0;
+                    hs1[q][c] = hs0;
+                }
+            }
+        }
+        // ---- update of ring i = m-2, azimuthal passes, velocities, store ----------------------
+        const int i = m - 2;
+        if (i >= r0 - 1 && i >= 0 && i < r1) {
+            const double invsurf = P.InvSurf[i];
+            double S[C], Q[4][C], E[C], V[C];
+            const double mean = P.vmean_c[i];
+            const double vconst = P.vconst_c[i];
+            const double vadd = P.fast_transport ? 0.0 : vconst;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double s0 = w[2][0][c];
+                S[c] = s0 + (F1[0][c] - F0[0][c]) * invsurf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    Q[q][c] = s0 * w[2][q + 1][c] + (F1[q + 1][c] - F0[q + 1][c]) * invsurf;
+                E[c] = ADI ? er[2][c] + (F1[NQ - 1][c] - F0[NQ - 1][c]) * invsurf : 0.0;
+                V[c] = vadd + (vp[2][c] - mean);
+            }
+            const double dxtheta = P.g_dxtheta[i];
+            const double invdx = P.g_inv_dxtheta[i];
+            const double geo_dt = P.g_dr_invsurf[i] * dt;
+            theta_pass<C, ADI, false, 0>(lim, 0, 0, geo_dt, dxtheta, invdx, dt, V, 0.0, S, Q, E);
+            if (P.fast_transport) {
+                if (vconst * dt > 0.0)
+                    theta_pass<C, ADI, false, 1>(lim, 0, 0, geo_dt, dxtheta, invdx, dt, V, vconst, S, Q, E);
+                else
+                    theta_pass<C, ADI, false, 2>(lim, 0, 0, geo_dt, dxtheta, invdx, dt, V, vconst, S, Q, E);
+            }
+            int ns = P.nshift_c[i] % nphi;
+            ns = ns < 0 ? ns + nphi : ns;
+            if (i >= r0) {
+                // the previous ring sits Nshift[i] - Nshift[i-1] lanes further right
+                int dsh = ns - ns_prev;
+                dsh = dsh > nphi / 2 ? dsh - nphi : (dsh < -(nphi / 2) ? dsh + nphi : dsh);
+                double rp[C], sp[C];
+                if (dsh == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        rp[c] = rmp_prev[c], sp[c] = S_prev[c];
+                } else if (dsh > 0) {
+                    const double rn = lane_next(rmp_prev[0]), sn = lane_next(S_prev[0]);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        rp[c] = c == C - 1 ? rn : rmp_prev[c == C - 1 ? c : c + 1];
+                        sp[c] = c == C - 1 ? sn : S_prev[c == C - 1 ? c : c + 1];
+                    }
+                } else {
+                    const double rl = lane_prev(rmp_prev[C - 1]), sl = lane_prev(S_prev[C - 1]);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        rp[c] = c == 0 ? rl : rmp_prev[c == 0 ? 0 : c - 1];
+                        sp[c] = c == 0 ? sl : S_prev[c == 0 ? 0 : c - 1];
+                    }
+                }
+                const double lp_l = lane_prev(Q[2][C - 1]); // L+ and Sigma of cell j-1
+                const double s_l = lane_prev(S[C - 1]);
+                const double fs = DAMP ? W.dfac_s[i] : 0.0, ts = DAMP ? W.dtau_s[i] : 1.0;
+                const int tvr = DAMP ? W.dtype_vr[i] : 0, tva = DAMP ? W.dtype_va[i] : 0;
+                const int tsg = DAMP ? W.dtype_sig[i] : 0, ten = DAMP ? W.dtype_e[i] : 0;
+                const double fv = DAMP ? W.dfac_v[i] : 0.0, tv = DAMP ? W.dtau_v[i] : 1.0;
+                const double invr = P.InvRmed[i], romega = P.g_r_omega[i];
+                const int row = i * nphi;
+                int jout[C];
+                double o_vr[C], o_va[C], o_s[C], o_e[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    int jo = jin[c] + ns;
+                    jout[c] = jo >= nphi ? jo - nphi : jo;
+                    const double lpm = c == 0 ? lp_l : Q[2][c == 0 ? 0 : c - 1];
+                    const double sm = c == 0 ? s_l : S[c == 0 ? 0 : c - 1];
+                    double vr = 0.0;
+                    if (i != 0)
+                        vr = (rp[c] + Q[1][c]) * fast_rcp(sp[c] + S[c]);
+                    double va = (lpm + Q[3][c]) * fast_rcp(sm + S[c]) * invr - romega;
+                    double sf = S[c] < P.sigma_floor_abs ? P.sigma_floor_abs : S[c];
+                    double e = ADI ? clamp_energy(P, E[c], sf) : 0.0;
+                    const int g = row + jout[c];
+                    if (DAMP) {
+                        vr = damp_value(W, vr, tvr, fv, tv, dt, W.vrad0, g, 0.0);
+                        va = damp_value(W, va, tva, fs, ts, dt, W.vazi0, g, 0.0);
+                        sf = damp_value(W, sf, tsg, fs, ts, dt, W.sigma0, g, W.sigma_floor_abs);
+                        if (ADI)
+                            e = damp_value(W, e, ten, fs, ts, dt, W.energy0, g, 0.0);
+                    }
+                    o_vr[c] = vr, o_va[c] = va, o_s[c] = sf, o_e[c] = e;
+                }
+                const bool pair_out = pair_valid && __builtin_amdgcn_ballot_w64(jout[C - 1] != jout[0] + 1) == 0;
+                if (pair_out) {
+                    if (valid[0]) {
+                        const int g = row + jout[0];
+                        ST2(W.vrad + g, (D2{o_vr[0], o_vr[C - 1]}));
+                        ST2(W.vazi + g, (D2{o_va[0], o_va[C - 1]}));
+                        ST2(W.sigma + g, (D2{o_s[0], o_s[C - 1]}));
+                        if (ADI)
+                            ST2(W.energy + g, (D2{o_e[0], o_e[C - 1]}));
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (valid[c]) {
+                            const int g = row + jout[c];
+                            W.vrad[g] = o_vr[c];
+                            W.vazi[g] = o_va[c];
+                            W.sigma[g] = o_s[c];
+                            if (ADI)
+                                W.energy[g] = o_e[c];
+                        }
+                }
+                if (i == nr - 1) { // v_r row Nr is not transported: it keeps its post-boundary value
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (valid[c]) {
+                            // row Nr is not shifted either: it is copied column by column
+                            double v = P.vrad[nr * nphi + jin[c]];
+                            if (DAMP)
+                                v = damp_value(W, v, W.dtype_vr[nr], W.dfac_v[nr], W.dtau_v[nr], dt, W.vrad0,
+                                               nr * nphi + jin[c], 0.0);
+                            W.vrad[nr * nphi + jin[c]] = v;
+                        }
+                }
+            }
+            ns_prev = ns;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                rmp_prev[c] = Q[0][c];
+                S_prev[c] = S[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                F1[q][c] = F0[q][c];
+            vr0[c] = vrn[c];
+        }
+    }
+    if (wave == 0 && lane == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
+        W.clk->time += dt;
+        W.clk->n_hydro_iter += 1;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2239,7 +2630,7 @@ int launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         else
             KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, l.grid, l.block, P);
     }
-    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(P.src_ring_nparts ? 64 : 256), P, 1,
+    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 1,
             P.src_ring_nparts ? (const double *)P.ring_part : (const double *)nullptr, P.src_ring_nparts, P.ring_pstride);
     ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     ThetaOut outA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
@@ -2348,7 +2739,7 @@ void launch_temperature(const Dev &P, hipStream_t st) { LAUNCH2D(KID_TEMPERATURE
 
 void launch_cfl(const Dev &P, int apply_policy, int use_part, hipStream_t st)
 {
-    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3(P.nr), dim3(use_part ? 64 : 256), P, 0,
+    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 0,
             use_part ? (const double *)P.cfl_ring_part : (const double *)nullptr, P.cfl_ring_nparts, P.ring_pstride);
     const int nrows = P.active_size - P.first_active;
     int nparts = 0;
