@@ -71,6 +71,18 @@ template <class T> int dev_alloc(fcpt_ctx *c, T **p, size_t n)
     return FCPT_OK;
 }
 
+template <class T> int dev_upload_raw(fcpt_ctx *c, const T **dst, const std::vector<T> &src)
+{
+    T *p = nullptr;
+    if (int e = dev_alloc(c, &p, src.size()))
+        return e;
+    if (hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("hipMemcpy of a per-ring table failed");
+        return FCPT_EHIP;
+    }
+    *dst = p;
+    return FCPT_OK;
+}
 int dev_upload(fcpt_ctx *c, const double **dst, const std::vector<double> &src)
 {
     double *p = nullptr;
@@ -251,10 +263,23 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt)
     apply_boundary_view(c, Q, false);
     if (frog)
         launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step (saved in cfl_dt)
-    const int marched = launch_transport(Q, P, st);
+    const TransportResult tr = launch_transport(Q, P, st);
     c->P.cfl_ring_nparts = 0;
-    if (!marched)
+    if (!tr.marched)
         launch_clock_advance(P.clk, st);
+    // the marching transport is out of place: the new state may sit in the scratch twins
+    if (tr.sigma != c->P.sigma)
+        std::swap(c->P.sigma, c->P.sigA);
+    if (tr.energy != c->P.energy)
+        std::swap(c->P.energy, c->P.eA);
+    if (tr.vrad != c->P.vrad)
+        std::swap(c->P.vrad, c->P.vrad_b);
+    if (tr.vazi != c->P.vazi)
+        std::swap(c->P.vazi, c->P.vazi_b);
+    c->grid[FCPT_F_SIGMA] = c->P.sigma;
+    c->grid[FCPT_F_VRAD] = c->P.vrad;
+    c->grid[FCPT_F_VAZI] = c->P.vazi;
+    c->grid[FCPT_F_ENERGY] = c->P.energy;
     if (frog) {
         launch_clock_scale_dt(P.clk, 2, 0.0, 0.5, st); // dt <- step/2
         enqueue_potential(c, true);
@@ -388,6 +413,22 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         if (!rc) rc = dev_upload(c, &P.g_inv_dxtheta.p, t2);
         if (!rc) rc = dev_upload(c, &P.g_dr_invsurf.p, t3);
         if (!rc) rc = dev_upload(c, &P.g_r_omega.p, t4);
+        std::vector<RadRow> rt(nr + 2);
+        for (int k = -1; k <= nr; ++k) {
+            const bool open = k > 0 && k < nr;
+            const int kk = open ? k : 1;
+            RadRow &r = rt[k + 1];
+            r.dr_lo = g.Rmed[kk] - g.Rmed[kk - 1];
+            r.dr_hi = g.Rmed[kk + 1] - g.Rmed[kk];
+            r.gphi = g.dphi * g.Rinf[kk];
+            r.idr_up = (k + 1 >= 1 && k + 1 <= nr - 1) ? g.InvDiffRmed[k + 1] : 0.0;
+        }
+        std::vector<ThetaRow> tt(nr);
+        for (int i = 0; i < nr; ++i)
+            tt[i] = ThetaRow{g.InvSurf[i], t1[i], t2[i], t3[i], g.InvRmed[i], t4[i], g.Rmed[i], 0.0};
+        if (!rc) rc = dev_upload_raw(c, &P.rad_tab, rt);
+        if (!rc) rc = dev_upload_raw(c, &P.theta_tab, tt);
+        if (!rc) rc = dev_alloc(c, &P.shift_tab, (size_t)nr);
     }
     {
         // isothermal alpha viscosity per ring, exactly as k_iso_cs_h + k_viscosity evaluate it:
@@ -414,7 +455,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     AL(qr, ns) AL(qphi, ns) AL(divv, ns) AL(trr, ns) AL(tpp, ns) AL(trp, nv) AL(qplus, ns) AL(qminus, ns)
     AL(rmpA, ns) AL(rmmA, ns) AL(lpA, ns) AL(lmA, ns) AL(sigA, ns) AL(eA, ns)
     AL(rmpB, ns) AL(rmmB, ns) AL(lpB, ns) AL(lmB, ns) AL(sigB, ns) AL(eB, ns)
-    AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1)
+    AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1) AL(shift_jump, 1)
     AL(cfl_part, (size_t)(nr + 256) * (size_t)((nphi + 255) / 256 + 1))
     P.ring_pstride = nphi / 32 + 4;
     AL(ring_part, (size_t)nr * P.ring_pstride) AL(cfl_ring_part, (size_t)nr * P.ring_pstride)
@@ -548,6 +589,10 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         if (!rc) rc = upi(P.dtype_va, ty[1]);
         if (!rc) rc = upi(P.dtype_sig, ty[2]);
         if (!rc) rc = upi(P.dtype_e, ty[3]);
+        std::vector<DampRow> dr(nr + 1);
+        for (int i = 0; i <= nr; ++i)
+            dr[i] = DampRow{fs[i], ts[i], fv[i], tv[i], ty[0][i], ty[1][i], ty[2][i], ty[3][i], {0.0, 0.0}};
+        if (!rc) rc = dev_upload_raw(c, &P.damp_tab, dr);
         if (rc) {
             fcpt_destroy(c);
             return rc;

@@ -74,6 +74,28 @@ struct CArrI {
 #endif
 };
 
+// Packed per-ring rows for the marching kernels: one wide scalar load (s_load_dwordx8/x16) per row
+// instead of one s_load + s_waitcnt per array, the dominant stall of a 2-3 waves/SIMD kernel.
+struct alignas(32) RadRow { // radial interface k, stored at index k + 1 (k = -1 .. nr)
+    double dr_lo;  // Rmed[k] - Rmed[k-1]   (k clamped to an open interface)
+    double dr_hi;  // Rmed[k+1] - Rmed[k]
+    double gphi;   // dphi * Rinf[k]
+    double idr_up; // InvDiffRmed[k+1] if rings k and k+1 both exist, else 0
+};
+struct alignas(64) ThetaRow { // ring i
+    double invsurf, dxtheta, inv_dxtheta, dr_invsurf, invr, r_omega, rmed, pad;
+};
+struct alignas(32) ShiftRow { // ring i, written by k_ring_mean
+    double mean, vconst;
+    int nshift, pad0;
+    double pad1;
+};
+struct alignas(64) DampRow { // ring i (nr + 1 rows: v_r has row nr)
+    double fs, ts, fv, tv;
+    int tvr, tva, tsg, ten;
+    double pad[2];
+};
+
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.
 struct Dev {
     int nr, nphi;
@@ -104,6 +126,11 @@ struct Dev {
     double *vconst; // per ring constant residual velocity
     int *nshift;    // per ring integer shift
     CArr vmean_c, vconst_c; // the same arrays for kernels that only read them
+    const RadRow *rad_tab;
+    const ThetaRow *theta_tab;
+    ShiftRow *shift_tab;
+    const DampRow *damp_tab;
+    int *shift_jump;        // set by k_transport_fused when |Nshift[i]-Nshift[i-1]| > 1 somewhere: the unfused kernels take over
     // wave damping folded into the end of the transport step: per-ring factor f = ((r-r_lim)/(r_edge-r_lim))^2
     // and time scale tau for scalar (dfac_s/dtau_s, nr) and vector (dfac_v/dtau_v, nr+1) grids, and the
     // per-ring damping type of each field (0 none, 1 reference, 2 zero)

@@ -15,7 +15,7 @@ enum KernelId {
     KID_VISC_VR, KID_QPLUS, KID_SUBSTEP3, KID_BOUNDARY, KID_DAMPING, KID_TRANSPORT_RADIAL,
     KID_RING_MEAN, KID_THETA1, KID_THETA2, KID_VELOCITIES, KID_CFL_INIT, KID_CFL_CELLS, KID_CLOCK,
     KID_SRC_FUSED, KID_AV_FUSED, KID_VISC_FUSED, KID_SOURCE_MARCH, KID_THETA_FUSED, KID_THETA_MARCH,
-    KID_COUNT
+    KID_TRANSPORT_FUSED, KID_COUNT
 };
 extern const char *const kKernelNames[KID_COUNT];
 
@@ -43,7 +43,15 @@ void launch_substep3(const Dev &P, int update_energy, hipStream_t st);
 void launch_boundary(const Dev &P, hipStream_t st);
 void launch_damping(const Dev &P, double *q, double *q0, const double *radius, const DampRange &r,
                     int is_density, hipStream_t st);
-int launch_transport(const Dev &P, const Dev &W, hipStream_t st);
+// Where Transport() left the new state: the marching kernels cannot work in place (neighbouring
+// wavefronts still read the old rings), so they write Sigma / e to the A scratch grids and the
+// velocities to whichever of vrad|vrad_b, vazi|vazi_b was not the input; the caller swaps the
+// context's pointers accordingly.
+struct TransportResult {
+    int marched;  // > 0: a marching kernel ran (new state complete, clock advanced)
+    double *sigma, *energy, *vrad, *vazi;
+};
+TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st);
 void launch_source_fused(const Dev &P, hipStream_t st);
 int launch_source_march(const Dev &P, hipStream_t st);
 void launch_viscous_fused(const Dev &P, hipStream_t st);

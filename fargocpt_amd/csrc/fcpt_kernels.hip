@@ -1196,8 +1196,10 @@ __device__ __forceinline__ RadialFlux radial_flux(const Dev &P, int k, double v,
     f.e = P.adiabatic ? g * star_radial(P, geo, v, dt, a.e, b.e, c.e, d.e) * rho * v : 0.0;
     return f;
 }
-template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(const Dev P)
+template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(const Dev P, const int *only_if)
 {
+    if (only_if && !*only_if) // fallback behind k_transport_fused: runs only when that kernel gave up
+        return;
     const int lb = xcd_block(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int j = (lb % gridDim.x) * blockDim.x + threadIdx.x;
     const int r0_ = ((lb / gridDim.x) * blockDim.y + threadIdx.y) * RADIAL_ROWS;
@@ -1294,12 +1296,18 @@ __global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, 
     if (lane == 0) {
         const double mean = acc / (double)P.nphi;
         P.vmean[i] = mean;
+        if (with_shift && i == 0)
+            *P.shift_jump = 0;
         if (with_shift) {
             const double invdt = 1.0 / dt;
             const double Ntilde = mean * invr * dt * P.invdphi;
             const double Nround = floor(Ntilde + 0.5);
             P.nshift[i] = (int)Nround;
-            P.vconst[i] = (Ntilde - Nround) * rmed * invdt * P.dphi;
+            const double vc = (Ntilde - Nround) * rmed * invdt * P.dphi;
+            P.vconst[i] = vc;
+            ShiftRow sr;
+            sr.mean = mean, sr.vconst = vc, sr.nshift = (int)Nround, sr.pad0 = 0, sr.pad1 = 0.0;
+            P.shift_tab[i] = sr;
         }
     }
 }
@@ -1764,9 +1772,11 @@ __device__ __forceinline__ void theta_pass(int lim, int lsrc_l, int lsrc_r, doub
 
 template <int C, bool ADI, bool DAMP, bool PER>
 __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const double *va_pre, const double *vr_pre, ThetaSet in,
-                                                              int tiles, int rows, int advance_clock)
+                                                              int tiles, int rows, int advance_clock, const int *only_if)
 {
     constexpr int periodic = PER ? 1 : 0;
+    if (only_if && !*only_if) // fallback behind k_transport_fused: runs only when that kernel gave up
+        return;
     // va_pre / vr_pre: the pre-transport (post-source, post-boundary) velocities; the new state goes to P's grids
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -1969,11 +1979,25 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
 // (10 + 11) doubles per cell for k_transport_radial + k_transport_theta_march.
 // Validity in cells of a 64*C segment: right 1 (L+ needs v_phi(j+1)), 4 at either end for the
 // two passes, left 1 for L+(j-1), 1 at either end for the v_r lane shift.
-#define TF_ROWS 16
+#define TF_ROWS 24
 template <int C> struct TfHalo {
     static constexpr int lo = C == 2 ? 6 : 5; // even for C = 2: a lane's two cells are final together
     static constexpr int hi = 6;
 };
+
+// packed per-ring rows through the constant address space (wide scalar loads)
+template <class T> __device__ __forceinline__ T crow_load(const T *tab, int i)
+{
+    static_assert(sizeof(T) % 8 == 0, "rows are made of 8-byte fields");
+    typedef const unsigned long long __attribute__((address_space(4))) *cptr;
+    cptr src = (cptr)__builtin_assume_aligned((const void *)(tab + i), alignof(T));
+    T out;
+    unsigned long long *dst = (unsigned long long *)&out;
+#pragma unroll
+    for (int n = 0; n < (int)(sizeof(T) / 8); ++n)
+        dst[n] = src[n];
+    return out;
+}
 
 template <int C, bool ADI, bool DAMP>
 __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows)
@@ -1981,8 +2005,6 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     constexpr int LO = TfHalo<C>::lo, HI = TfHalo<C>::hi;
     constexpr int NQ = ADI ? 6 : 5; // s, rmp, rmm, lp, lm(, e)
-    if (*P.shift_jump)
-        return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chunk = wave / tiles;
@@ -1991,6 +2013,27 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
     if (r0 >= nr)
         return;
     const int r1 = r0 + rows < nr ? r0 + rows : nr;
+    if (wave == 0 && lane == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
+        W.clk->time += P.clk->dt;
+        W.clk->n_hydro_iter += 1;
+    }
+    { // the lane shift of the previous ring covers |Nshift[i] - Nshift[i-1]| <= 1 only
+        bool jump = false;
+        int prev = P.nshift_c[r0 > 0 ? r0 - 1 : 0] % nphi;
+        for (int i = r0; i < r1; ++i) {
+            const int cur = P.nshift_c[i] % nphi;
+            int dd = cur - prev;
+            dd = dd < 0 ? -dd : dd;
+            dd = dd > nphi / 2 ? nphi - dd : dd;
+            jump = jump || dd > 1;
+            prev = cur;
+        }
+        if (jump) {
+            if (lane == 0)
+                *P.shift_jump = 1;
+            return;
+        }
+    }
     const int tile = wave - chunk * tiles;
     const int stride = 64 * C - (LO + HI);
     const int a = tile * stride - LO; // first pre-shift column of the segment
@@ -2026,28 +2069,103 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
         er[0][c] = er[1][c] = er[2][c] = vp[0][c] = vp[1][c] = vp[2][c] = 0.0;
         vr0[c] = vr1[c] = rmp_prev[c] = S_prev[c] = 0.0;
     }
-    auto load_vr = [&](int k, double (&out)[C]) {
-        if (k < 0 || k > nr) {
+    // raw loads of one ring: Sigma(k), v_phi(k)(, e(k)) and v_r(k+1); zeros outside the grid
+    struct RingRaw {
+        double sg[C], va[C], en[C], vr[C];
+    };
+    auto fetch = [&](int k, RingRaw &o) {
+        const bool in_k = k >= 0 && k < nr;
+        const bool in_v = k + 1 >= 0 && k + 1 <= nr;
 #pragma unroll
-            for (int c = 0; c < C; ++c)
-                out[c] = 0.0;
-            return;
-        }
-        const double *row = P.vrad + (size_t)k * nphi;
+        for (int c = 0; c < C; ++c)
+            o.sg[c] = o.va[c] = o.en[c] = o.vr[c] = 0.0;
+        const size_t row = (size_t)(in_k ? k : 0) * nphi, rowv = (size_t)(in_v ? k + 1 : 0) * nphi;
         if (pair_in) {
-            const D2 v = LD2(row + jin[0]);
-            out[0] = v.x, out[C - 1] = v.y;
+            if (in_k) {
+                const D2 s2 = LD2(P.sigma + row + jin[0]), v2 = LD2(P.vazi + row + jin[0]);
+                o.sg[0] = s2.x, o.sg[C - 1] = s2.y, o.va[0] = v2.x, o.va[C - 1] = v2.y;
+                if (ADI) {
+                    const D2 e2 = LD2(P.energy + row + jin[0]);
+                    o.en[0] = e2.x, o.en[C - 1] = e2.y;
+                }
+            }
+            if (in_v) {
+                const D2 r2 = LD2(P.vrad + rowv + jin[0]);
+                o.vr[0] = r2.x, o.vr[C - 1] = r2.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (in_k) {
+                    o.sg[c] = P.sigma[row + jin[c]];
+                    o.va[c] = P.vazi[row + jin[c]];
+                    if (ADI)
+                        o.en[c] = P.energy[row + jin[c]];
+                }
+                if (in_v)
+                    o.vr[c] = P.vrad[rowv + jin[c]];
+            }
+        }
+    };
+    {
+        RingRaw t;
+        fetch(r0 - 4, t); // only its v_r(r0-3) is used
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            vr0[c] = t.vr[c];
+    }
+    // Software pipeline of the memory traffic.  The loads of ring m+1 are issued one iteration
+    // before their first use, and the stores of an iteration are held back until the next loads
+    // are in flight: the single s_waitcnt vmcnt(0) per iteration then only meets operations that
+    // are a whole iteration old (vmcnt counts stores too; waiting right behind them costs a
+    // round trip per ring at 2-3 waves per SIMD).
+    RingRaw nxt;
+    fetch(r0 - 3, nxt);
+    int ns_prev = 0;
+    bool pend = false, pend_pair = false; // deferred stores of the previous iteration
+    int pend_g[C];
+    double p_vr[C], p_va[C], p_s[C], p_e[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        pend_g[c] = 0, p_vr[c] = p_va[c] = p_s[c] = p_e[c] = 0.0;
+    auto flush = [&]() {
+        if (!pend)
+            return;
+        if (pend_pair) {
+            if (valid[0]) {
+                ST2(W.vrad + pend_g[0], (D2{p_vr[0], p_vr[C - 1]}));
+                ST2(W.vazi + pend_g[0], (D2{p_va[0], p_va[C - 1]}));
+                ST2(W.sigma + pend_g[0], (D2{p_s[0], p_s[C - 1]}));
+                if (ADI)
+                    ST2(W.energy + pend_g[0], (D2{p_e[0], p_e[C - 1]}));
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                out[c] = row[jin[c]];
+                if (valid[c]) {
+                    W.vrad[pend_g[c]] = p_vr[c];
+                    W.vazi[pend_g[c]] = p_va[c];
+                    W.sigma[pend_g[c]] = p_s[c];
+                    if (ADI)
+                        W.energy[pend_g[c]] = p_e[c];
+                }
         }
+        pend = false;
     };
-    load_vr(r0 - 3, vr0);
-    int ns_prev = 0;
 
     for (int m = r0 - 3; m <= r1 + 1; ++m) {
-        // ---- rotate the window and load ring m ------------------------------------------------
+        // ---- per-ring scalars of this iteration in one batch ----------------------------------
+        const int k = m - 1, i = m - 2;
+        const bool in_m = m >= 0 && m < nr;
+        const bool do_i = i >= r0 - 1 && i >= 0 && i < r1;
+        const ThetaRow tm = crow_load(P.theta_tab, in_m ? m : 0);
+        const RadRow rk = crow_load(P.rad_tab, (k < -1 ? -1 : k) + 1);
+        const ThetaRow ti = crow_load(P.theta_tab, do_i ? i : 0);
+        const ShiftRow si = crow_load((const ShiftRow *)P.shift_tab, do_i ? i : 0);
+        DampRow di;
+        if (DAMP)
+            di = crow_load(W.damp_tab, do_i ? i : 0);
+        // ---- rotate the window, take ring m, start the loads of ring m+1, then last stores ----
 #pragma unroll
         for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -2057,71 +2175,47 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
             }
             er[2][c] = er[1][c], er[1][c] = er[0][c];
             vp[2][c] = vp[1][c], vp[1][c] = vp[0][c];
-            vr1[c] = vr0[c];
         }
         double vrn[C]; // v_r(m+1)
-        load_vr(m + 1, vrn);
-        const bool in_m = m >= 0 && m < nr;
-        if (in_m) {
-            const size_t row = (size_t)m * nphi;
+        {
             double sg[C], va[C], en[C];
-            if (pair_in) {
-                const D2 s2 = LD2(P.sigma + row + jin[0]), v2 = LD2(P.vazi + row + jin[0]);
-                D2 e2 = {0.0, 0.0};
-                if (ADI)
-                    e2 = LD2(P.energy + row + jin[0]);
-                sg[0] = s2.x, sg[C - 1] = s2.y, va[0] = v2.x, va[C - 1] = v2.y, en[0] = e2.x, en[C - 1] = e2.y;
-            } else {
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    sg[c] = P.sigma[row + jin[c]];
-                    va[c] = P.vazi[row + jin[c]];
-                    en[c] = ADI ? P.energy[row + jin[c]] : 0.0;
-                }
-            }
-            const double r = P.Rmed[m], romega = P.g_r_omega[m];
+            for (int c = 0; c < C; ++c)
+                sg[c] = nxt.sg[c], va[c] = nxt.va[c], en[c] = nxt.en[c], vrn[c] = nxt.vr[c];
+            if (m < r1 + 1)
+                fetch(m + 1, nxt);
+            flush();
+            const double r = tm.rmed, romega = tm.r_omega;
             const double va_n = lane_next(va[0]); // v_phi of cell j+1 of the last cell of the lane
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const double van = c == C - 1 ? va_n : va[c == C - 1 ? c : c + 1];
                 w[0][0][c] = sg[c];
-                w[0][1][c] = vrn[c];                 // rm+ / Sigma = v_r(m+1)   (:484-485)
-                w[0][2][c] = vr0[c];                 // rm- / Sigma = v_r(m)
-                w[0][3][c] = (van + romega) * r;     // L+ / Sigma = (v_phi(j+1) + r Omega) r
-                w[0][4][c] = (va[c] + romega) * r;   // L- / Sigma
+                w[0][1][c] = in_m ? vrn[c] : 0.0;                      // rm+ / Sigma = v_r(m+1)   (:484-485)
+                w[0][2][c] = in_m ? vr0[c] : 0.0;                      // rm- / Sigma = v_r(m)
+                w[0][3][c] = in_m ? (van + romega) * r : 0.0;          // L+ / Sigma = (v_phi(j+1) + r Omega) r
+                w[0][4][c] = in_m ? (va[c] + romega) * r : 0.0;        // L- / Sigma
                 if (ADI) {
-                    w[0][NQ - 1][c] = en[c] * fast_rcp(sg[c]);
+                    w[0][NQ - 1][c] = in_m ? en[c] * fast_rcp(sg[c]) : 0.0;
                     er[0][c] = en[c];
                 }
                 vp[0][c] = va[c];
             }
-        } else {
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    w[0][q][c] = 0.0;
-                er[0][c] = vp[0][c] = 0.0;
-            }
         }
         // ---- R: slopes of ring m-1, fluxes through interface k = m-1 --------------------------
-        const int k = m - 1;
         double F0[NQ][C];
         {
-            const bool kin = m >= 1 && m <= nr - 1;          // rings m-1 and m both exist
-            const double idr_m = kin ? P.InvDiffRmed[m] : 0.0; // 1 / (Rmed[m] - Rmed[m-1])
-            const bool lim_ok = k > 0 && k < nr - 1;          // boundary rings carry no slope (:360-372)
-            const bool open = k > 0 && k < nr;                // interface carries a flux
-            const int kk = open ? k : 1;
-            const double dr_lo = P.Rmed[kk] - P.Rmed[kk - 1], dr_hi = P.Rmed[kk + 1] - P.Rmed[kk];
-            const double g = dt * P.dphi * P.Rinf[kk];
+            const double idr_m = rk.idr_up;          // 1 / (Rmed[m] - Rmed[m-1]) when both rings exist
+            const bool lim_ok = k > 0 && k < nr - 1; // boundary rings carry no slope (:360-372)
+            const bool open = k > 0 && k < nr;       // interface carries a flux
+            const double g = dt * rk.gphi;
             bool up[C];
             double dist[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const double v = vr1[c]; // v_r(m-1)
                 up[c] = v > 0.0;
-                dist[c] = up[c] ? (dr_lo - v * dt) : -(dr_hi + v * dt);
+                dist[c] = up[c] ? (rk.dr_lo - v * dt) : -(rk.dr_hi + v * dt);
             }
             double Fc[C];
 #pragma unroll
@@ -2142,13 +2236,12 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                 }
             }
         }
-        // ---- update of ring i = m-2, azimuthal passes, velocities, store ----------------------
-        const int i = m - 2;
-        if (i >= r0 - 1 && i >= 0 && i < r1) {
-            const double invsurf = P.InvSurf[i];
+        // ---- update of ring i = m-2, azimuthal passes, velocities -----------------------------
+        if (do_i) {
+            const double invsurf = ti.invsurf;
             double S[C], Q[4][C], E[C], V[C];
-            const double mean = P.vmean_c[i];
-            const double vconst = P.vconst_c[i];
+            const double mean = si.mean;
+            const double vconst = si.vconst;
             const double vadd = P.fast_transport ? 0.0 : vconst;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -2160,9 +2253,9 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                 E[c] = ADI ? er[2][c] + (F1[NQ - 1][c] - F0[NQ - 1][c]) * invsurf : 0.0;
                 V[c] = vadd + (vp[2][c] - mean);
             }
-            const double dxtheta = P.g_dxtheta[i];
-            const double invdx = P.g_inv_dxtheta[i];
-            const double geo_dt = P.g_dr_invsurf[i] * dt;
+            const double dxtheta = ti.dxtheta;
+            const double invdx = ti.inv_dxtheta;
+            const double geo_dt = ti.dr_invsurf * dt;
             theta_pass<C, ADI, false, 0>(lim, 0, 0, geo_dt, dxtheta, invdx, dt, V, 0.0, S, Q, E);
             if (P.fast_transport) {
                 if (vconst * dt > 0.0)
@@ -2170,7 +2263,7 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                 else
                     theta_pass<C, ADI, false, 2>(lim, 0, 0, geo_dt, dxtheta, invdx, dt, V, vconst, S, Q, E);
             }
-            int ns = P.nshift_c[i] % nphi;
+            int ns = si.nshift % nphi;
             ns = ns < 0 ? ns + nphi : ns;
             if (i >= r0) {
                 // the previous ring sits Nshift[i] - Nshift[i-1] lanes further right
@@ -2198,14 +2291,13 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                 }
                 const double lp_l = lane_prev(Q[2][C - 1]); // L+ and Sigma of cell j-1
                 const double s_l = lane_prev(S[C - 1]);
-                const double fs = DAMP ? W.dfac_s[i] : 0.0, ts = DAMP ? W.dtau_s[i] : 1.0;
-                const int tvr = DAMP ? W.dtype_vr[i] : 0, tva = DAMP ? W.dtype_va[i] : 0;
-                const int tsg = DAMP ? W.dtype_sig[i] : 0, ten = DAMP ? W.dtype_e[i] : 0;
-                const double fv = DAMP ? W.dfac_v[i] : 0.0, tv = DAMP ? W.dtau_v[i] : 1.0;
-                const double invr = P.InvRmed[i], romega = P.g_r_omega[i];
+                const double fs = DAMP ? di.fs : 0.0, ts = DAMP ? di.ts : 1.0;
+                const int tvr = DAMP ? di.tvr : 0, tva = DAMP ? di.tva : 0;
+                const int tsg = DAMP ? di.tsg : 0, ten = DAMP ? di.ten : 0;
+                const double fv = DAMP ? di.fv : 0.0, tv = DAMP ? di.tv : 1.0;
+                const double invr = ti.invr, romega = ti.r_omega;
                 const int row = i * nphi;
                 int jout[C];
-                double o_vr[C], o_va[C], o_s[C], o_e[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     int jo = jin[c] + ns;
@@ -2226,39 +2318,20 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                         if (ADI)
                             e = damp_value(W, e, ten, fs, ts, dt, W.energy0, g, 0.0);
                     }
-                    o_vr[c] = vr, o_va[c] = va, o_s[c] = sf, o_e[c] = e;
+                    p_vr[c] = vr, p_va[c] = va, p_s[c] = sf, p_e[c] = e;
+                    pend_g[c] = g;
                 }
-                const bool pair_out = pair_valid && __builtin_amdgcn_ballot_w64(jout[C - 1] != jout[0] + 1) == 0;
-                if (pair_out) {
-                    if (valid[0]) {
-                        const int g = row + jout[0];
-                        ST2(W.vrad + g, (D2{o_vr[0], o_vr[C - 1]}));
-                        ST2(W.vazi + g, (D2{o_va[0], o_va[C - 1]}));
-                        ST2(W.sigma + g, (D2{o_s[0], o_s[C - 1]}));
-                        if (ADI)
-                            ST2(W.energy + g, (D2{o_e[0], o_e[C - 1]}));
-                    }
-                } else {
+                pend = true;
+                pend_pair = pair_valid && __builtin_amdgcn_ballot_w64(jout[C - 1] != jout[0] + 1) == 0;
+                if (i == nr - 1) { // v_r row Nr is neither transported nor shifted: copied column by column
 #pragma unroll
                     for (int c = 0; c < C; ++c)
                         if (valid[c]) {
-                            const int g = row + jout[c];
-                            W.vrad[g] = o_vr[c];
-                            W.vazi[g] = o_va[c];
-                            W.sigma[g] = o_s[c];
-                            if (ADI)
-                                W.energy[g] = o_e[c];
-                        }
-                }
-                if (i == nr - 1) { // v_r row Nr is not transported: it keeps its post-boundary value
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        if (valid[c]) {
-                            // row Nr is not shifted either: it is copied column by column
                             double v = P.vrad[nr * nphi + jin[c]];
-                            if (DAMP)
-                                v = damp_value(W, v, W.dtype_vr[nr], W.dfac_v[nr], W.dtau_v[nr], dt, W.vrad0,
-                                               nr * nphi + jin[c], 0.0);
+                            if (DAMP) {
+                                const DampRow dn = crow_load(W.damp_tab, nr);
+                                v = damp_value(W, v, dn.tvr, dn.fv, dn.tv, dt, W.vrad0, nr * nphi + jin[c], 0.0);
+                            }
                             W.vrad[nr * nphi + jin[c]] = v;
                         }
                 }
@@ -2275,13 +2348,11 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
                 F1[q][c] = F0[q][c];
+            vr1[c] = vr0[c];
             vr0[c] = vrn[c];
         }
     }
-    if (wave == 0 && lane == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
-        W.clk->time += dt;
-        W.clk->n_hydro_iter += 1;
-    }
+    flush();
 }
 
 // ---------------------------------------------------------------------------
@@ -2447,7 +2518,7 @@ const char *const kKernelNames[KID_COUNT] = {
     "k_visc_vr", "k_qplus_qminus", "k_substep3", "k_boundary", "k_damping", "k_transport_radial",
     "k_ring_mean", "k_transport_theta1", "k_transport_theta2", "k_velocities", "k_cfl_final",
     "k_cfl_cells", "k_clock", "k_src_fused", "k_av_fused", "k_visc_fused", "k_source_march",
-    "k_transport_theta_fused", "k_transport_theta_march"};
+    "k_transport_theta_fused", "k_transport_theta_march", "k_transport_fused"};
 
 thread_local Profiler *g_prof = nullptr;
 
@@ -2618,20 +2689,122 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
             r.redge, r.tau, is_density);
 }
 
-int launch_transport(const Dev &P, const Dev &W, hipStream_t st)
+// one radial sweep + ring means (T1-T4); only_if: see k_transport_radial
+static void launch_radial(const Dev &P, const int *only_if, hipStream_t st)
 {
-    int marched_tiles = 0; // > 0: the marching kernel ran (new state, clock advance and CFL partial sums done)
-    // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
-    // Transport, TransportEuler.cpp:112-136
-    {
-        const Launch2D l = launch2d((P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS, P.nphi);
-        if (l.block.x >= 64)
-            KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<true>, l.grid, l.block, P);
-        else
-            KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, l.grid, l.block, P);
-    }
+    const Launch2D l = launch2d((P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS, P.nphi);
+    if (l.block.x >= 64)
+        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<true>, l.grid, l.block, P, only_if);
+    else
+        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, l.grid, l.block, P, only_if);
+}
+static void launch_shift_means(const Dev &P, hipStream_t st)
+{
     KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 1,
             P.src_ring_nparts ? (const double *)P.ring_part : (const double *)nullptr, P.src_ring_nparts, P.ring_pstride);
+}
+#define MARCHK(CC, PP, AA, DD)                                                                                      \
+    KLAUNCH(KID_THETA_MARCH, (k_transport_theta_march<CC, AA, DD, PP>), grid, block, Wm, (const double *)P.vazi,   \
+            (const double *)P.vrad, inB, tiles, rows, advance, only_if)
+#define MARCHC(CC, PP)                   \
+    if (P.adiabatic) {                   \
+        if (Wm.damp_in_step)             \
+            MARCHK(CC, PP, true, true);  \
+        else                             \
+            MARCHK(CC, PP, true, false); \
+    } else {                             \
+        if (Wm.damp_in_step)             \
+            MARCHK(CC, PP, false, true); \
+        else                             \
+            MARCHK(CC, PP, false, false);\
+    }
+// azimuthal marching kernel on set B -> state grids of Wm; returns the tile count
+static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, int advance, const int *only_if,
+                              hipStream_t st)
+{
+    ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
+    const int tstride = 64 * C - (THETA_LO + THETA_HI);
+    const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
+    int rows = THETA_ROWS;
+    if (const char *e = getenv("FCPT_THETA_ROWS"))
+        rows = atoi(e) > 0 ? atoi(e) : rows;
+    const int chunks = (P.nr + rows - 1) / rows;
+    const int waves = chunks * tiles;
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (!periodic) { // tiled: 2 cells per lane (1, 4 and 6 were measured slower), DPP lane shifts
+        MARCHC(2, false)
+    } else if (C == 1) {
+        MARCHC(1, true)
+    } else if (C == 2) {
+        MARCHC(2, true)
+    } else {
+        MARCHC(4, true)
+    }
+    return tiles;
+}
+#undef MARCHC
+#undef MARCHK
+
+TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st)
+{
+    // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
+    // Transport, TransportEuler.cpp:112-136
+    TransportResult res = {0, W.sigma, W.energy, W.vrad, W.vazi};
+    // ---- everything in one kernel (tiled rings only) ------------------------------------------
+    int CF = P.nphi >= 256 ? 1 : 0; // 1 cell per lane: 3 waves per SIMD (2 cells: 284 VGPRs, 1 wave)
+    if (const char *e = getenv("FCPT_TRANSPORT_FUSED")) { // 0: off, 1 / 2: cells per lane
+        const int v = atoi(e);
+        CF = v == 0 ? 0 : ((v == 1 || v == 2) && P.nphi >= 128 * v ? v : CF);
+    }
+    if (CF) {
+        Dev Wm = W; // the marching kernels cannot work in place
+        Wm.sigma = W.sigA;
+        Wm.energy = W.eA;
+        Wm.vrad = P.vrad == W.vrad ? W.vrad_b : W.vrad;
+        Wm.vazi = P.vazi == W.vazi ? W.vazi_b : W.vazi;
+        launch_shift_means(P, st);
+        int rows = TF_ROWS;
+        if (const char *e = getenv("FCPT_TRANSPORT_ROWS"))
+            rows = atoi(e) > 0 ? atoi(e) : rows;
+        const int tstride = 64 * CF - (CF == 2 ? TfHalo<2>::lo + TfHalo<2>::hi : TfHalo<1>::lo + TfHalo<1>::hi);
+        const int tiles = (P.nphi + tstride - 1) / tstride;
+        const int chunks = (P.nr + rows - 1) / rows;
+        const dim3 grid((chunks * tiles + 3) / 4), block(256);
+#define TFK(CC, AA, DD) KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD>), grid, block, P, Wm, tiles, rows)
+#define TFC(CC)               \
+    if (P.adiabatic) {        \
+        if (W.damp_in_step)   \
+            TFK(CC, true, true);  \
+        else                  \
+            TFK(CC, true, false); \
+    } else {                  \
+        if (W.damp_in_step)   \
+            TFK(CC, false, true); \
+        else                  \
+            TFK(CC, false, false);\
+    }
+        if (CF == 2) {
+            TFC(2)
+        } else {
+            TFC(1)
+        }
+#undef TFC
+#undef TFK
+        // behind it, the two-kernel form: its blocks return at once unless the fused kernel met
+        // |Nshift[i] - Nshift[i-1]| > 1 (a time step beyond the FARGO shear limit)
+        bool fallback = true;
+        if (const char *e = getenv("FCPT_TRANSPORT_FALLBACK"))
+            fallback = e[0] != '0';
+        if (fallback) {
+            launch_radial(P, P.shift_jump, st);
+            launch_theta_march(P, Wm, 2, 0, 0, P.shift_jump, st);
+        }
+        res.marched = tiles;
+        res.sigma = Wm.sigma, res.energy = Wm.energy, res.vrad = Wm.vrad, res.vazi = Wm.vazi;
+        return res;
+    }
+    launch_radial(P, nullptr, st);
+    launch_shift_means(P, st);
     ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     ThetaOut outA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
     ThetaSet inA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
@@ -2652,41 +2825,7 @@ int launch_transport(const Dev &P, const Dev &W, hipStream_t st)
     if (const char *e = getenv("FCPT_THETA_MARCH"))
         march = march && e[0] != '0';
     if (march) {
-        const int tstride = 64 * C - (THETA_LO + THETA_HI);
-        const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
-        int rows = THETA_ROWS;
-        if (const char *e = getenv("FCPT_THETA_ROWS"))
-            rows = atoi(e) > 0 ? atoi(e) : rows;
-        const int chunks = (P.nr + rows - 1) / rows;
-        const int waves = chunks * tiles;
-        marched_tiles = tiles;
-        const dim3 grid((waves + 3) / 4), block(256);
-#define MARCHK(CC, PP, AA, DD)                                                                                   \
-    KLAUNCH(KID_THETA_MARCH, (k_transport_theta_march<CC, AA, DD, PP>), grid, block, W, (const double *)P.vazi, \
-            (const double *)P.vrad, inB, tiles, rows, 1)
-#define MARCHC(CC, PP)                   \
-    if (P.adiabatic) {                   \
-        if (W.damp_in_step)              \
-            MARCHK(CC, PP, true, true);  \
-        else                             \
-            MARCHK(CC, PP, true, false); \
-    } else {                             \
-        if (W.damp_in_step)              \
-            MARCHK(CC, PP, false, true); \
-        else                             \
-            MARCHK(CC, PP, false, false);\
-    }
-        if (!periodic) { // tiled: 2 cells per lane (1, 4 and 6 were measured slower), DPP lane shifts
-            MARCHC(2, false)
-        } else if (C == 1) {
-            MARCHC(1, true)
-        } else if (C == 2) {
-            MARCHC(2, true)
-        } else {
-            MARCHC(4, true)
-        }
-#undef MARCHC
-#undef MARCHK
+        res.marched = launch_theta_march(P, W, C, periodic, 1, nullptr, st);
     } else if (C) {
         const int tstride = 64 * C - 2 * THETA_HALO;
         const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
@@ -2717,7 +2856,7 @@ int launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         else
             LAUNCH2D_T(KID_VELOCITIES, k_velocities, false, P.nr, W, inB, (const double *)P.vrad);
     }
-    return marched_tiles;
+    return res;
 }
 
 void launch_derived(const Dev &P, hipStream_t st)
