@@ -85,10 +85,11 @@ struct alignas(32) RadRow { // radial interface k, stored at index k + 1 (k = -1
 struct alignas(64) ThetaRow { // ring i
     double invsurf, dxtheta, inv_dxtheta, dr_invsurf, invr, r_omega, rmed, pad;
 };
-struct alignas(32) ShiftRow { // ring i, written by k_ring_mean
+struct alignas(64) ShiftRow { // ring i, written by k_ring_mean (transport call)
     double mean, vconst;
+    double es, ev, ev_top; // exp(-dt f / tau) of the wave damping: cell-centred, v_r, v_r row i+1 (last ring only)
     int nshift, pad0;
-    double pad1;
+    double pad1[2];
 };
 struct alignas(64) DampRow { // ring i (nr + 1 rows: v_r has row nr)
     double fs, ts, fv, tv;

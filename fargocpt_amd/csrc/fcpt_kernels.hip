@@ -1306,7 +1306,15 @@ __global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, 
             const double vc = (Ntilde - Nround) * rmed * invdt * P.dphi;
             P.vconst[i] = vc;
             ShiftRow sr;
-            sr.mean = mean, sr.vconst = vc, sr.nshift = (int)Nround, sr.pad0 = 0, sr.pad1 = 0.0;
+            sr.mean = mean, sr.vconst = vc, sr.nshift = (int)Nround, sr.pad0 = 0, sr.pad1[0] = sr.pad1[1] = 0.0;
+            const DampRow dr = P.damp_tab[i]; // damping.cpp:311-427: X <- (X - X0) exp(-dt f / tau) + X0
+            sr.es = exp(-dt * dr.fs / dr.ts);
+            sr.ev = exp(-dt * dr.fv / dr.tv);
+            sr.ev_top = 1.0;
+            if (i == P.nr - 1) {
+                const DampRow dn = P.damp_tab[P.nr];
+                sr.ev_top = exp(-dt * dn.fv / dn.tv);
+            }
             P.shift_tab[i] = sr;
         }
     }
@@ -1999,12 +2007,22 @@ template <class T> __device__ __forceinline__ T crow_load(const T *tab, int i)
     return out;
 }
 
-template <int C, bool ADI, bool DAMP>
+// wave damping with the ring's precomputed exp(-dt f / tau) (k_ring_mean): types as damp_value
+__device__ __forceinline__ double damp_apply(double X, int type, double ef, const double *ref, int cell, double zero_target)
+{
+    if (type == 0)
+        return X;
+    const double X0 = type == 1 ? ref[cell] : zero_target;
+    return (X - X0) * ef + X0;
+}
+
+template <int C, bool ADI, bool DAMP, int LIM>
 __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     constexpr int LO = TfHalo<C>::lo, HI = TfHalo<C>::hi;
     constexpr int NQ = ADI ? 6 : 5; // s, rmp, rmm, lp, lm(, e)
+    constexpr int lim = LIM;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chunk = wave / tiles;
@@ -2038,7 +2056,6 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
     const int stride = 64 * C - (LO + HI);
     const int a = tile * stride - LO; // first pre-shift column of the segment
     const double dt = P.clk->dt;
-    const int lim = P.limiter;
     auto wrap = [nphi](int j) { return j < 0 ? j + nphi : (j >= nphi ? j - nphi : j); };
 
     int jin[C];
@@ -2053,13 +2070,12 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
     const bool pair_valid = C == 2 && __builtin_amdgcn_ballot_w64(valid[0] != valid[C - 1]) == 0;
 
     // rolling window: index 0 = ring m (newest), 1 = m-1, 2 = m-2
-    double w[3][NQ][C];  // specific quantities (w[.][0] = Sigma itself; energy: e / Sigma)
+    double w[3][NQ][C];  // specific quantities: Sigma, v_r(ring+1), v_r(ring), (v_phi(j+1) + r Omega) r, (v_phi + r Omega) r(, e / Sigma)
     double er[3][C];     // the energy itself
     double vp[3][C];     // v_phi as loaded
     double d1[NQ][C];    // (w(m-1) - w(m-2)) InvDiffRmed[m-1]
     double hs1[NQ][C];   // limited half slope of ring m-2
     double F1[NQ][C];    // flux through interface m-2
-    double vr0[C], vr1[C]; // v_r(m), v_r(m-1)
     double rmp_prev[C], S_prev[C]; // transported rm+ and Sigma of the previous ring
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -2067,7 +2083,7 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
         for (int q = 0; q < NQ; ++q)
             w[0][q][c] = w[1][q][c] = w[2][q][c] = d1[q][c] = hs1[q][c] = F1[q][c] = 0.0;
         er[0][c] = er[1][c] = er[2][c] = vp[0][c] = vp[1][c] = vp[2][c] = 0.0;
-        vr0[c] = vr1[c] = rmp_prev[c] = S_prev[c] = 0.0;
+        rmp_prev[c] = S_prev[c] = 0.0;
     }
     // raw loads of one ring: Sigma(k), v_phi(k)(, e(k)) and v_r(k+1); zeros outside the grid
     struct RingRaw {
@@ -2107,101 +2123,54 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
             }
         }
     };
-    {
-        RingRaw t;
-        fetch(r0 - 4, t); // only its v_r(r0-3) is used
+    // ring k (raw) -> newest window slot; vr_k = v_r(k) from the previous ring's fetch
+    double vr_last[C];
+    auto convert = [&](int k, const RingRaw &o) {
+        const bool in_k = k >= 0 && k < nr;
+        const ThetaRow tk = crow_load(P.theta_tab, in_k ? k : 0);
+        const double r = tk.rmed, romega = tk.r_omega;
+        const double va_n = lane_next(o.va[0]); // v_phi of cell j+1 of the last cell of the lane
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-            vr0[c] = t.vr[c];
-    }
-    // Software pipeline of the memory traffic.  The loads of ring m+1 are issued one iteration
-    // before their first use, and the stores of an iteration are held back until the next loads
-    // are in flight: the single s_waitcnt vmcnt(0) per iteration then only meets operations that
-    // are a whole iteration old (vmcnt counts stores too; waiting right behind them costs a
-    // round trip per ring at 2-3 waves per SIMD).
+        for (int c = 0; c < C; ++c) {
+            const double van = c == C - 1 ? va_n : o.va[c == C - 1 ? c : c + 1];
+            w[0][0][c] = o.sg[c];
+            w[0][1][c] = in_k ? o.vr[c] : 0.0;                        // rm+ / Sigma = v_r(k+1)   (:484-485)
+            w[0][2][c] = in_k ? vr_last[c] : 0.0;                     // rm- / Sigma = v_r(k)
+            w[0][3][c] = in_k ? (van + romega) * r : 0.0;             // L+ / Sigma = (v_phi(j+1) + r Omega) r
+            w[0][4][c] = in_k ? (o.va[c] + romega) * r : 0.0;         // L- / Sigma
+            if (ADI) {
+                w[0][NQ - 1][c] = in_k ? o.en[c] * fast_rcp(o.sg[c]) : 0.0;
+                er[0][c] = o.en[c];
+            }
+            vp[0][c] = o.va[c];
+            vr_last[c] = o.vr[c];
+        }
+    };
+    // Software pipeline of the memory traffic: ring m+1 is in flight while ring m-2 is computed;
+    // at the bottom of an iteration the arrived ring is converted, the loads of ring m+2 are
+    // issued, and only then the iteration's stores.  The one s_waitcnt vmcnt(0) per iteration then
+    // meets operations that are a whole compute phase old (vmcnt counts stores too; waiting right
+    // behind them costs a round trip per ring at 2-3 waves per SIMD).
     RingRaw nxt;
-    fetch(r0 - 3, nxt);
-    int ns_prev = 0;
-    bool pend = false, pend_pair = false; // deferred stores of the previous iteration
-    int pend_g[C];
-    double p_vr[C], p_va[C], p_s[C], p_e[C];
+    fetch(r0 - 4, nxt);
 #pragma unroll
     for (int c = 0; c < C; ++c)
-        pend_g[c] = 0, p_vr[c] = p_va[c] = p_s[c] = p_e[c] = 0.0;
-    auto flush = [&]() {
-        if (!pend)
-            return;
-        if (pend_pair) {
-            if (valid[0]) {
-                ST2(W.vrad + pend_g[0], (D2{p_vr[0], p_vr[C - 1]}));
-                ST2(W.vazi + pend_g[0], (D2{p_va[0], p_va[C - 1]}));
-                ST2(W.sigma + pend_g[0], (D2{p_s[0], p_s[C - 1]}));
-                if (ADI)
-                    ST2(W.energy + pend_g[0], (D2{p_e[0], p_e[C - 1]}));
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                if (valid[c]) {
-                    W.vrad[pend_g[c]] = p_vr[c];
-                    W.vazi[pend_g[c]] = p_va[c];
-                    W.sigma[pend_g[c]] = p_s[c];
-                    if (ADI)
-                        W.energy[pend_g[c]] = p_e[c];
-                }
-        }
-        pend = false;
-    };
+        vr_last[c] = nxt.vr[c]; // v_r(r0-3)
+    fetch(r0 - 3, nxt);
+    convert(r0 - 3, nxt);
+    fetch(r0 - 2, nxt);
+    int ns_prev = 0;
 
     for (int m = r0 - 3; m <= r1 + 1; ++m) {
         // ---- per-ring scalars of this iteration in one batch ----------------------------------
         const int k = m - 1, i = m - 2;
-        const bool in_m = m >= 0 && m < nr;
         const bool do_i = i >= r0 - 1 && i >= 0 && i < r1;
-        const ThetaRow tm = crow_load(P.theta_tab, in_m ? m : 0);
         const RadRow rk = crow_load(P.rad_tab, (k < -1 ? -1 : k) + 1);
         const ThetaRow ti = crow_load(P.theta_tab, do_i ? i : 0);
         const ShiftRow si = crow_load((const ShiftRow *)P.shift_tab, do_i ? i : 0);
         DampRow di;
         if (DAMP)
             di = crow_load(W.damp_tab, do_i ? i : 0);
-        // ---- rotate the window, take ring m, start the loads of ring m+1, then last stores ----
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                w[2][q][c] = w[1][q][c];
-                w[1][q][c] = w[0][q][c];
-            }
-            er[2][c] = er[1][c], er[1][c] = er[0][c];
-            vp[2][c] = vp[1][c], vp[1][c] = vp[0][c];
-        }
-        double vrn[C]; // v_r(m+1)
-        {
-            double sg[C], va[C], en[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                sg[c] = nxt.sg[c], va[c] = nxt.va[c], en[c] = nxt.en[c], vrn[c] = nxt.vr[c];
-            if (m < r1 + 1)
-                fetch(m + 1, nxt);
-            flush();
-            const double r = tm.rmed, romega = tm.r_omega;
-            const double va_n = lane_next(va[0]); // v_phi of cell j+1 of the last cell of the lane
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const double van = c == C - 1 ? va_n : va[c == C - 1 ? c : c + 1];
-                w[0][0][c] = sg[c];
-                w[0][1][c] = in_m ? vrn[c] : 0.0;                      // rm+ / Sigma = v_r(m+1)   (:484-485)
-                w[0][2][c] = in_m ? vr0[c] : 0.0;                      // rm- / Sigma = v_r(m)
-                w[0][3][c] = in_m ? (van + romega) * r : 0.0;          // L+ / Sigma = (v_phi(j+1) + r Omega) r
-                w[0][4][c] = in_m ? (va[c] + romega) * r : 0.0;        // L- / Sigma
-                if (ADI) {
-                    w[0][NQ - 1][c] = in_m ? en[c] * fast_rcp(sg[c]) : 0.0;
-                    er[0][c] = en[c];
-                }
-                vp[0][c] = va[c];
-            }
-        }
         // ---- R: slopes of ring m-1, fluxes through interface k = m-1 --------------------------
         double F0[NQ][C];
         {
@@ -2213,7 +2182,7 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
             double dist[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const double v = vr1[c]; // v_r(m-1)
+                const double v = w[1][2][c]; // v_r(m-1)
                 up[c] = v > 0.0;
                 dist[c] = up[c] ? (rk.dr_lo - v * dt) : -(rk.dr_hi + v * dt);
             }
@@ -2226,7 +2195,7 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                     const double hs0 = lim_ok ? half_limiter(lim, d0, d1[q][c]) : 0.0; // ring m-1
                     const double st = (up[c] ? w[2][q][c] : w[1][q][c]) + dist[c] * (up[c] ? hs1[q][c] : hs0);
                     if (q == 0) {
-                        Fc[c] = open ? g * st * vr1[c] : 0.0; // mass flux g rho* v
+                        Fc[c] = open ? g * st * w[1][2][c] : 0.0; // mass flux g rho* v
                         F0[q][c] = Fc[c];
                     } else {
                         F0[q][c] = st * Fc[c];
@@ -2237,6 +2206,12 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
             }
         }
         // ---- update of ring i = m-2, azimuthal passes, velocities -----------------------------
+        bool out_on = false, out_pair = false;
+        int out_g[C];
+        double o_vr[C], o_va[C], o_s[C], o_e[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            out_g[c] = 0, o_vr[c] = o_va[c] = o_s[c] = o_e[c] = 0.0;
         if (do_i) {
             const double invsurf = ti.invsurf;
             double S[C], Q[4][C], E[C], V[C];
@@ -2291,10 +2266,6 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                 }
                 const double lp_l = lane_prev(Q[2][C - 1]); // L+ and Sigma of cell j-1
                 const double s_l = lane_prev(S[C - 1]);
-                const double fs = DAMP ? di.fs : 0.0, ts = DAMP ? di.ts : 1.0;
-                const int tvr = DAMP ? di.tvr : 0, tva = DAMP ? di.tva : 0;
-                const int tsg = DAMP ? di.tsg : 0, ten = DAMP ? di.ten : 0;
-                const double fv = DAMP ? di.fv : 0.0, tv = DAMP ? di.tv : 1.0;
                 const double invr = ti.invr, romega = ti.r_omega;
                 const int row = i * nphi;
                 int jout[C];
@@ -2312,29 +2283,17 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                     double e = ADI ? clamp_energy(P, E[c], sf) : 0.0;
                     const int g = row + jout[c];
                     if (DAMP) {
-                        vr = damp_value(W, vr, tvr, fv, tv, dt, W.vrad0, g, 0.0);
-                        va = damp_value(W, va, tva, fs, ts, dt, W.vazi0, g, 0.0);
-                        sf = damp_value(W, sf, tsg, fs, ts, dt, W.sigma0, g, W.sigma_floor_abs);
+                        vr = damp_apply(vr, di.tvr, si.ev, W.vrad0, g, 0.0);
+                        va = damp_apply(va, di.tva, si.es, W.vazi0, g, 0.0);
+                        sf = damp_apply(sf, di.tsg, si.es, W.sigma0, g, W.sigma_floor_abs);
                         if (ADI)
-                            e = damp_value(W, e, ten, fs, ts, dt, W.energy0, g, 0.0);
+                            e = damp_apply(e, di.ten, si.es, W.energy0, g, 0.0);
                     }
-                    p_vr[c] = vr, p_va[c] = va, p_s[c] = sf, p_e[c] = e;
-                    pend_g[c] = g;
+                    o_vr[c] = vr, o_va[c] = va, o_s[c] = sf, o_e[c] = e;
+                    out_g[c] = g;
                 }
-                pend = true;
-                pend_pair = pair_valid && __builtin_amdgcn_ballot_w64(jout[C - 1] != jout[0] + 1) == 0;
-                if (i == nr - 1) { // v_r row Nr is neither transported nor shifted: copied column by column
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        if (valid[c]) {
-                            double v = P.vrad[nr * nphi + jin[c]];
-                            if (DAMP) {
-                                const DampRow dn = crow_load(W.damp_tab, nr);
-                                v = damp_value(W, v, dn.tvr, dn.fv, dn.tv, dt, W.vrad0, nr * nphi + jin[c], 0.0);
-                            }
-                            W.vrad[nr * nphi + jin[c]] = v;
-                        }
-                }
+                out_on = true;
+                out_pair = pair_valid && __builtin_amdgcn_ballot_w64(jout[C - 1] != jout[0] + 1) == 0;
             }
             ns_prev = ns;
 #pragma unroll
@@ -2343,16 +2302,57 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                 S_prev[c] = S[c];
             }
         }
+        // ---- bottom: rotate, take ring m+1, start ring m+2, then this iteration's stores ------
 #pragma unroll
         for (int c = 0; c < C; ++c) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q)
+            for (int q = 0; q < NQ; ++q) {
+                w[2][q][c] = w[1][q][c];
+                w[1][q][c] = w[0][q][c];
                 F1[q][c] = F0[q][c];
-            vr1[c] = vr0[c];
-            vr0[c] = vrn[c];
+            }
+            er[2][c] = er[1][c], er[1][c] = er[0][c];
+            vp[2][c] = vp[1][c], vp[1][c] = vp[0][c];
+        }
+        if (m < r1 + 1) {
+            convert(m + 1, nxt);
+            if (m < r1)
+                fetch(m + 2, nxt);
+        }
+        if (out_on) {
+            if (out_pair) {
+                if (valid[0]) {
+                    ST2(W.vrad + out_g[0], (D2{o_vr[0], o_vr[C - 1]}));
+                    ST2(W.vazi + out_g[0], (D2{o_va[0], o_va[C - 1]}));
+                    ST2(W.sigma + out_g[0], (D2{o_s[0], o_s[C - 1]}));
+                    if (ADI)
+                        ST2(W.energy + out_g[0], (D2{o_e[0], o_e[C - 1]}));
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (valid[c]) {
+                        W.vrad[out_g[c]] = o_vr[c];
+                        W.vazi[out_g[c]] = o_va[c];
+                        W.sigma[out_g[c]] = o_s[c];
+                        if (ADI)
+                            W.energy[out_g[c]] = o_e[c];
+                    }
+            }
+            if (i == nr - 1) { // v_r row Nr is neither transported nor shifted: copied column by column
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (valid[c]) {
+                        double v = P.vrad[nr * nphi + jin[c]];
+                        if (DAMP) {
+                            const DampRow dn = crow_load(W.damp_tab, nr);
+                            v = damp_apply(v, dn.tvr, si.ev_top, W.vrad0, nr * nphi + jin[c], 0.0);
+                        }
+                        W.vrad[nr * nphi + jin[c]] = v;
+                    }
+            }
         }
     }
-    flush();
 }
 
 // ---------------------------------------------------------------------------
@@ -2770,7 +2770,11 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         const int tiles = (P.nphi + tstride - 1) / tstride;
         const int chunks = (P.nr + rows - 1) / rows;
         const dim3 grid((chunks * tiles + 3) / 4), block(256);
-#define TFK(CC, AA, DD) KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD>), grid, block, P, Wm, tiles, rows)
+#define TFK(CC, AA, DD)                                                                                             \
+    if (P.limiter == FCPT_LIMITER_MC)                                                                                \
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows); \
+    else                                                                                                             \
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows)
 #define TFC(CC)               \
     if (P.adiabatic) {        \
         if (W.damp_in_step)   \
