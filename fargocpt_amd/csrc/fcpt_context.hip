@@ -430,10 +430,10 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         if (!rc) rc = dev_upload_raw(c, &P.theta_tab, tt);
         if (!rc) rc = dev_alloc(c, &P.shift_tab, (size_t)nr);
     }
+    std::vector<double> nu_ring(nr);
     {
         // isothermal alpha viscosity per ring, exactly as k_iso_cs_h + k_viscosity evaluate it:
         // H = cs * (1 / Omega_K), nu = alpha * H * cs
-        std::vector<double> nu_ring(nr);
         for (int i = 0; i < nr; ++i) {
             const double r = c->geo.Rmed[i];
             const double inv_omega_kepler = 1.0 / std::sqrt(d->G * d->hydro_center_mass / (r * r * r));
@@ -442,6 +442,86 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         }
         if (!rc)
             rc = dev_upload(c, &P.nu_ring.p, nu_ring);
+    }
+    {
+        // per-iteration rows of the marching source kernel (k_source_march): every per-ring factor
+        // with the index expression and operation order of the kernel's former array reads
+        const HostGeometry &g = c->geo;
+        auto at = [](const std::vector<double> &v, int i) { return (i >= 0 && i < (int)v.size()) ? v[i] : 0.0; };
+        auto crow = [nr](int r) { return r < 0 ? 0 : (r > nr - 1 ? nr - 1 : r); };
+        const bool alpha = d->viscous_alpha > 0;
+        auto nu_of = [&](int r) { return alpha ? nu_ring[crow(r)] : d->constant_viscosity; };
+        const double C2 = d->artificial_viscosity_factor * d->artificial_viscosity_factor;
+        std::vector<SrcRow> rows(nr + 8);
+        for (int m = -2; m <= nr + 5; ++m) {
+            SrcRow &R = rows[m + 2];
+            std::memset(&R, 0, sizeof(R));
+            {
+                const int rc0 = crow(m), rc1 = crow(m - 1);
+                R.cs2_m = cs_ring[rc0] * cs_ring[rc0];
+                R.cs2_m1 = cs_ring[rc1] * cs_ring[rc1];
+                R.idr_m = at(g.InvDiffRmed, m);
+                R.rinf_om_m = at(g.Rinf, m) * d->omega_frame;
+                R.inv_rinf_m = at(g.InvRinf, m);
+                R.inv_dxt_m = (m >= 0 && m <= nr) ? 2.0 / (g.dphi * (g.Rsup[m] + g.Rinf[m])) : 0.0;
+            }
+            {
+                const int r = crow(m - 1);
+                R.inv_drsup_b = g.InvDiffRsup[r];
+                R.inv_rmed_b = g.InvRmed[r];
+                const double Dr = g.Rinf[r + 1] - g.Rinf[r];
+                const double rDphi = g.Rmed[r] * g.dphi;
+                const double dx = nphi <= 16 ? std::min(Dr, rDphi) : std::max(Dr, rDphi);
+                R.lsq_b = C2 * (dx * dx);
+            }
+            {
+                const int r = m - 1;
+                if (r >= 1 && r <= nr) {
+                    R.inv_rsum_c = 1.0 / (g.Rsup[r] + g.Rinf[r]);
+                    R.rmed_c = g.Rmed[r];
+                    R.rmed_cm1 = g.Rmed[r - 1];
+                    R.inv_drmed2_c = 1.0 / (g.Rmed[r] * g.Rmed[r] - g.Rmed[r - 1] * g.Rmed[r - 1]);
+                }
+                R.idr_c = at(g.InvDiffRmed, r);
+                R.inv_dxtheta_c = at(g.InvRmed, r) * g.invdphi;
+            }
+            {
+                const int r = crow(m - 2);
+                R.rinf_d1 = g.Rinf[r + 1];
+                R.rinf_d0 = g.Rinf[r];
+                R.inv_drsuprb_d = g.InvDiffRsupRb[r];
+                R.inv_rmed_d = g.InvRmed[r];
+                R.inv_drsup_d = g.InvDiffRsup[r];
+                R.nu_d = nu_of(m - 2);
+            }
+            {
+                const int r = m - 1;
+                if (r >= 1 && r <= nr - 1) {
+                    R.inv_rmed_r = g.InvRmed[r];
+                    R.inv_rmed_rm1 = g.InvRmed[r - 1];
+                    R.idr_r = g.InvDiffRmed[r];
+                    R.rinf_r = g.Rinf[r];
+                    R.inv_rinf_r = g.InvRinf[r];
+                    const double nu1 = nu_of(r), nu2 = nu_of(r - 1);
+                    R.nu_avg_r = 0.25 * (nu1 + nu2 + nu1 + nu2);
+                }
+            }
+            {
+                const int k = m - 2;
+                if (k >= 1 && k <= nr) {
+                    const double ra1 = at(g.Rinf, k + 1), ra0 = g.Rinf[k];
+                    R.inv_rmed_k = at(g.InvRmed, k);
+                    R.two_inv_dra2_k = 2.0 * (1.0 / (ra1 * ra1 - ra0 * ra0));
+                    R.ra1sq_k = ra1 * ra1;
+                    R.ra0sq_k = ra0 * ra0;
+                    R.inv_rmsum_k = 1.0 / (g.Rmed[k] + g.Rmed[k - 1]);
+                    R.rmed_k = g.Rmed[k];
+                    R.rmed_km1 = g.Rmed[k - 1];
+                    R.idr_k = at(g.InvDiffRmed, k);
+                }
+            }
+        }
+        if (!rc) rc = dev_upload_raw(c, &P.src_tab, rows);
     }
 
     const size_t ns = (size_t)nr * nphi, nv = (size_t)(nr + 1) * nphi;

@@ -82,6 +82,23 @@ struct alignas(32) RadRow { // radial interface k, stored at index k + 1 (k = -1
     double gphi;   // dphi * Rinf[k]
     double idr_up; // InvDiffRmed[k+1] if rings k and k+1 both exist, else 0
 };
+// everything iteration m of k_source_march needs (rings m, m-1, m-2), stored at index m + 2;
+// fields of rings outside the grid are 0 and guarded by the kernel's row-range tests
+struct alignas(64) SrcRow {
+    // stage A, ring m
+    double cs2_m, cs2_m1, idr_m, rinf_om_m, inv_rinf_m, inv_dxt_m;
+    // stage B, ring crow(m-1)
+    double inv_drsup_b, inv_rmed_b, lsq_b;
+    // stage C, ring m-1
+    double inv_rsum_c, rmed_c, rmed_cm1, inv_drmed2_c, idr_c, inv_dxtheta_c;
+    // stage D, diagonal on ring crow(m-2), r-phi on ring m-1
+    double rinf_d1, rinf_d0, inv_drsuprb_d, inv_rmed_d, inv_drsup_d, nu_d;
+    double inv_rmed_r, inv_rmed_rm1, idr_r, rinf_r, inv_rinf_r, nu_avg_r;
+    // stage E, ring k = m-2
+    double inv_rmed_k, two_inv_dra2_k, ra1sq_k, ra0sq_k, inv_rmsum_k, rmed_k, rmed_km1, idr_k;
+    double pad[5];
+};
+static_assert(sizeof(SrcRow) == 320, "SrcRow is five 64-byte scalar loads");
 struct alignas(64) ThetaRow { // ring i
     double invsurf, dxtheta, inv_dxtheta, dr_invsurf, invr, r_omega, rmed, pad;
 };
@@ -127,6 +144,7 @@ struct Dev {
     double *vconst; // per ring constant residual velocity
     int *nshift;    // per ring integer shift
     CArr vmean_c, vconst_c; // the same arrays for kernels that only read them
+    const SrcRow *src_tab;
     const RadRow *rad_tab;
     const ThetaRow *theta_tab;
     ShiftRow *shift_tab;

@@ -56,6 +56,20 @@ typedef D2v __attribute__((aligned(8))) D2;
 #define ST2(p_, v_) (*(D2 *)(p_) = (v_))
 #endif
 
+// packed per-ring rows through the constant address space (wide scalar loads)
+template <class T> __device__ __forceinline__ T crow_load(const T *tab, int i)
+{
+    static_assert(sizeof(T) % 8 == 0, "rows are made of 8-byte fields");
+    typedef const unsigned long long __attribute__((address_space(4))) *cptr;
+    cptr src = (cptr)__builtin_assume_aligned((const void *)(tab + i), alignof(T));
+    T out;
+    unsigned long long *dst = (unsigned long long *)&out;
+#pragma unroll
+    for (int n = 0; n < (int)(sizeof(T) / 8); ++n)
+        dst[n] = src[n];
+    return out;
+}
+
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The marching kernels
 // give every XCD a contiguous range of logical blocks, so that neighbouring phi tiles and ring
 // chunks -- which read the same halo cells -- meet in one L2 instead of fetching them twice from
@@ -729,14 +743,12 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
     const int j = jraw < 0 ? jraw + nphi : (jraw >= nphi ? jraw - nphi : jraw);
     const bool store_lane = lane >= MARCH_LO && lane < MARCH_LO + MARCH_VALID && jraw < nphi;
     const double dt = P.clk->dt;
-    const double OmF = P.omega_frame;
     const double C2 = P.art_visc_factor * P.art_visc_factor;
 
 #define NEXT(x) lane_next(x) /* value of cell j+1 */
 #define PREV(x) lane_prev(x) /* value of cell j-1 */
     auto crow = [nr](int r) { return r < 0 ? 0 : (r > nr - 1 ? nr - 1 : r); };   // cell rows
     auto vrow = [nr](int r) { return r < 0 ? 0 : (r > nr ? nr : r); };           // v_r rows
-    auto nu_of = [&](int r) { return P.alpha_viscosity ? P.nu_ring[crow(r)] : P.nu_const; };
 
     // rolling state (suffix _1.._3 = rings m-1..m-3)
     double S_m = 0, S_1 = 0, S_2 = 0, S_3 = 0, Sp_m = 0, Sp_1 = 0, Sp_2 = 0; // Sigma and Sigma(j-1)
@@ -762,6 +774,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
     double pVa = P.vazi[IDX(crow(rn), j)], pVr = P.vrad[IDX(vrow(rn), j)];
 
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
+        const SrcRow R = crow_load(P.src_tab, m + 2); // every per-ring factor of this iteration, one batch
         // ---- shift the window, take the prefetched ring m, prefetch ring m+1 ------------
         S_3 = S_2; S_2 = S_1; S_1 = S_m; Sp_2 = Sp_1; Sp_1 = Sp_m;
         F_1 = F_m;
@@ -783,23 +796,21 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
         // ---- A: source terms on ring m ---------------------------------------------------
         {
             const int r = m;
-            const int rc = crow(r), rc1 = crow(r - 1);
-            const double cs_m = P.cs_ring[rc], cs_1 = P.cs_ring[rc1];
-            const double P_m = S_m * (cs_m * cs_m), P_1 = S_1 * (cs_1 * cs_1), Pp_m = Sp_m * (cs_m * cs_m);
+            const double P_m = S_m * R.cs2_m, P_1 = S_1 * R.cs2_m1, Pp_m = Sp_m * R.cs2_m;
             vr1_m = vr0_m;
             if (r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr) {
                 double gradp = 2.0 * fast_rcp(S_m + S_1);
                 gradp *= (P_m - P_1);
-                gradp *= P.InvDiffRmed[r];
-                const double gradphi = (F_m - F_1) * P.InvDiffRmed[r];
+                gradp *= R.idr_m;
+                const double gradphi = (F_m - F_1) * R.idr_m;
                 const double vsum = va0_m + va0n_m + va0_1 + va0n_1;
-                const double vt = 0.25 * vsum + P.Rinf[r] * OmF;
+                const double vt = 0.25 * vsum + R.rinf_om_m;
                 const double vt2 = vt * vt;
-                vr1_m = vr0_m + dt * (-gradp - gradphi + vt2 * P.InvRinf[r]);
+                vr1_m = vr0_m + dt * (-gradp - gradphi + vt2 * R.inv_rinf_m);
             }
             va1_m = va0_m;
             if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
-                const double invdxtheta = P.g_inv_dxt_src[r]; // 2 / (dphi (Rsup + Rinf))
+                const double invdxtheta = R.inv_dxt_m; // 2 / (dphi (Rsup + Rinf))
                 const double gradp = 2.0 * fast_rcp(S_m + Sp_m) * (P_m - Pp_m) * invdxtheta;
                 const double gradphi = (F_m - Fp_m) * invdxtheta;
                 va1_m = va0_m + dt * (-gradp - gradphi);
@@ -808,16 +819,12 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
         // ---- B: artificial pressure on ring m-1 ------------------------------------------
         qr_2 = qr_1; qp_2 = qp_1;
         {
-            const int r = crow(m - 1);
             const double va1n_1 = NEXT(va1_1);
             if (AV == 1) {
-                const double eps_rr = (vr1_m - vr1_1) * P.InvDiffRsup[r];
-                const double eps_pp = P.InvRmed[r] * ((va1n_1 - va1_1) * P.invdphi + 0.5 * (vr1_m + vr1_1));
+                const double eps_rr = (vr1_m - vr1_1) * R.inv_drsup_b;
+                const double eps_pp = R.inv_rmed_b * ((va1n_1 - va1_1) * P.invdphi + 0.5 * (vr1_m + vr1_1));
                 const double div_V = dmin(eps_rr + eps_pp, 0.0);
-                const double Dr = P.Rinf[r + 1] - P.Rinf[r];
-                const double rDphi = P.Rmed[r] * P.dphi;
-                const double dx = nphi <= 16 ? dmin(Dr, rDphi) : dmax(Dr, rDphi);
-                const double l_sq = C2 * (dx * dx);
+                const double l_sq = R.lsq_b;
                 qr_1 = l_sq * S_1 * -div_V * (eps_rr - 1.0 / 3.0 * div_V);
                 qp_1 = l_sq * S_1 * -div_V * (eps_pp - 1.0 / 3.0 * div_V);
             } else if (AV == 2) {
@@ -838,20 +845,20 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                 const double qpp_p = PREV(qp_1);
                 if (r >= 1 && r < nr - 1) {
                     const double sigma_phi_avg = 0.5 * (S_1 + Sp_1);
-                    va2_1 = va1_1 + 2.0 * dt * (P.g_inv_rsum[r] * fast_rcp(sigma_phi_avg)) * (qp_1 - qpp_p) * P.invdphi;
+                    va2_1 = va1_1 + 2.0 * dt * (R.inv_rsum_c * fast_rcp(sigma_phi_avg)) * (qp_1 - qpp_p) * P.invdphi;
                 }
                 if (upd_vr) {
                     const double sigma_r_avg = 0.5 * (S_1 + S_2);
-                    const double rm = P.Rmed[r], rmm = P.Rmed[r - 1];
-                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt * fast_rcp(sigma_r_avg) * 2.0 * P.g_inv_drmed2[r] *
+                    const double rm = R.rmed_c, rmm = R.rmed_cm1;
+                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt * fast_rcp(sigma_r_avg) * 2.0 * R.inv_drmed2_c *
                                         ((qr_1 * rm - qr_2 * rmm) - 0.5 * (qp_1 + qp_2) * (rm - rmm));
                 }
             } else if (AV == 2) {
                 const double qphi_p = PREV(qp_1);
                 if (upd_vr)
-                    vr2_1 = vr1_1 - dt * 2.0 * fast_rcp(S_1 + S_2) * (qr_1 - qr_2) * P.InvDiffRmed[r];
+                    vr2_1 = vr1_1 - dt * 2.0 * fast_rcp(S_1 + S_2) * (qr_1 - qr_2) * R.idr_c;
                 if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
-                    const double invdxtheta = P.InvRmed[r] * P.invdphi;
+                    const double invdxtheta = R.inv_dxtheta_c;
                     va2_1 = va1_1 - dt * 2.0 * fast_rcp(S_1 + Sp_1) * (qp_1 - qphi_p) * invdxtheta;
                 }
             }
@@ -859,15 +866,14 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
         // ---- D: stress tensor: diagonal on ring m-2, r-phi on ring m-1 --------------------
         trr_3 = trr_2; tpp_3 = tpp_2; trp_2 = trp_1;
         {
-            const int r = crow(m - 2);
             const double va2n_2 = NEXT(va2_2);
             const double dva = va2n_2 - va2_2;
             const double divv =
-                (vr2_1 * P.Rinf[r + 1] - vr2_2 * P.Rinf[r]) * P.InvDiffRsupRb[r] + dva * P.invdphi * P.InvRmed[r];
-            const double nu = nu_of(m - 2);
-            const double drr = (vr2_1 - vr2_2) * P.InvDiffRsup[r];
+                (vr2_1 * R.rinf_d1 - vr2_2 * R.rinf_d0) * R.inv_drsuprb_d + dva * P.invdphi * R.inv_rmed_d;
+            const double nu = R.nu_d;
+            const double drr = (vr2_1 - vr2_2) * R.inv_drsup_d;
             trr_2 = 2.0 * nu * S_2 * (drr - 1.0 / 3.0 * divv);
-            const double dpp = dva * P.invdphi * P.InvRmed[r] + 0.5 * (vr2_1 + vr2_2) * P.InvRmed[r];
+            const double dpp = dva * P.invdphi * R.inv_rmed_d + 0.5 * (vr2_1 + vr2_2) * R.inv_rmed_d;
             tpp_2 = 2.0 * nu * S_2 * (dpp - 1.0 / 3.0 * divv);
         }
         {
@@ -875,11 +881,10 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
             const double vr2p_1 = PREV(vr2_1);
             trp_1 = 0.0;
             if (r >= 1 && r <= nr - 1) {
-                const double dvazirdr = (va2_1 * P.InvRmed[r] - va2_2 * P.InvRmed[r - 1]) * P.InvDiffRmed[r];
+                const double dvazirdr = (va2_1 * R.inv_rmed_r - va2_2 * R.inv_rmed_rm1) * R.idr_r;
                 const double dvrdphi = (vr2_1 - vr2p_1) * P.invdphi;
-                const double drp = P.Rinf[r] * dvazirdr + dvrdphi * P.InvRinf[r];
-                const double nu1 = nu_of(r), nu2 = nu_of(r - 1);
-                const double nu = 0.25 * (nu1 + nu2 + nu1 + nu2);
+                const double drp = R.rinf_r * dvazirdr + dvrdphi * R.inv_rinf_r;
+                const double nu = R.nu_avg_r;
                 const double sigma = 0.25 * (S_1 + S_2 + Sp_1 + Sp_2);
                 trp_1 = nu * sigma * drp;
             }
@@ -893,15 +898,14 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                 double vr3 = vr2_2, va3 = va2_2;
                 if (k >= 1 && k < nr - 1) {
                     const double sigma_avg = 0.5 * (S_2 + Sp_2);
-                    const double ra1 = P.Rinf[k + 1], ra0 = P.Rinf[k];
-                    va3 = va2_2 + dt * P.InvRmed[k] * fast_rcp(sigma_avg) *
-                                      ((2.0 * P.g_inv_dra2[k]) * (ra1 * ra1 * trp_1 - ra0 * ra0 * trp_2) +
+                    va3 = va2_2 + dt * R.inv_rmed_k * fast_rcp(sigma_avg) *
+                                      (R.two_inv_dra2_k * (R.ra1sq_k * trp_1 - R.ra0sq_k * trp_2) +
                                        (tpp_2 - tpp_p) * P.invdphi);
                 }
                 if (k >= P.one_no_ghost_vr && k < P.maxmo_no_ghost_vr) {
                     const double sigma_avg = 0.5 * (S_2 + S_3);
-                    vr3 = vr2_2 + dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * P.g_inv_rmsum[k] *
-                                      ((P.Rmed[k] * trr_2 - P.Rmed[k - 1] * trr_3) * P.InvDiffRmed[k] +
+                    vr3 = vr2_2 + dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
+                                      ((R.rmed_k * trr_2 - R.rmed_km1 * trr_3) * R.idr_k +
                                        (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
                 }
                 if (store_lane) {
@@ -1992,20 +1996,6 @@ template <int C> struct TfHalo {
     static constexpr int lo = C == 2 ? 6 : 5; // even for C = 2: a lane's two cells are final together
     static constexpr int hi = 6;
 };
-
-// packed per-ring rows through the constant address space (wide scalar loads)
-template <class T> __device__ __forceinline__ T crow_load(const T *tab, int i)
-{
-    static_assert(sizeof(T) % 8 == 0, "rows are made of 8-byte fields");
-    typedef const unsigned long long __attribute__((address_space(4))) *cptr;
-    cptr src = (cptr)__builtin_assume_aligned((const void *)(tab + i), alignof(T));
-    T out;
-    unsigned long long *dst = (unsigned long long *)&out;
-#pragma unroll
-    for (int n = 0; n < (int)(sizeof(T) / 8); ++n)
-        dst[n] = src[n];
-    return out;
-}
 
 // wave damping with the ring's precomputed exp(-dt f / tau) (k_ring_mean): types as damp_value
 __device__ __forceinline__ double damp_apply(double X, int type, double ef, const double *ref, int cell, double zero_target)
