@@ -37,6 +37,7 @@ struct fcpt_ctx {
     Profiler prof;
     bool profiling = false;
     bool fused_source = true;
+    int src_parts = 0; // segments of ring sums left by the last k_source_march
     bool march_source = true;
     bool stepped = false; // fcpt_step ran since the last fcpt_post
     bool pressure_valid = false;
@@ -198,6 +199,7 @@ bool enqueue_kick(fcpt_ctx *c)
     hipStream_t st = c->stream;
     if (c->fused_source) {
         const int segs = c->march_source ? launch_source_march(P, st) : 0; // one pass: (v) -> (v_b)
+        c->src_parts = segs > 0 ? segs : 0;
         if (!segs) {
             ensure_pressure(c);
             launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
@@ -259,12 +261,13 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt)
         Q.vrad = P.vrad_b;
         Q.vazi = P.vazi_b;
     }
-    Q.src_ring_nparts = 0;
+    Q.src_ring_nparts = in_b ? c->src_parts : 0; // ring sums of v_phi left by k_source_march
+    c->src_parts = 0;
     apply_boundary_view(c, Q, false);
     if (frog)
         launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step (saved in cfl_dt)
     const TransportResult tr = launch_transport(Q, P, st);
-    c->P.cfl_ring_nparts = 0;
+    c->P.cfl_ring_nparts = frog ? 0 : tr.cfl_parts; // leapfrog kicks v_phi once more
     if (!tr.marched)
         launch_clock_advance(P.clk, st);
     // the marching transport is out of place: the new state may sit in the scratch twins

@@ -49,6 +49,7 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
 // context's pointers accordingly.
 struct TransportResult {
     int marched;  // > 0: a marching kernel ran (new state complete, clock advanced)
+    int cfl_parts; // > 0: per-tile ring sums of the new v_phi are in cfl_ring_part
     double *sigma, *energy, *vrad, *vazi;
 };
 TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st);

@@ -120,6 +120,27 @@ template <int CTRL> __device__ __forceinline__ double dpp_shift(double x)
 }
 __device__ __forceinline__ double lane_prev(double x) { return dpp_shift<0x138>(x); }
 __device__ __forceinline__ double lane_next(double x) { return dpp_shift<0x130>(x); }
+// Sum over the wavefront in a fixed tree order (deterministic), all in the VALU: DPP row shifts
+// build the 16-lane row sums, row_bcast:15 / row_bcast:31 fold the four rows.  The total is valid
+// in lane 63.  (The ds_bpermute butterfly costs six dependent LDS round trips per call.)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_add(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    // bound_ctrl: lanes without a source (and rows masked out) contribute 0
+    const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return x + __hiloint2double(shi, slo);
+}
+__device__ __forceinline__ double wave_sum(double x)
+{
+    x = dpp_add<0x111, 0xf>(x); // row_shr:1
+    x = dpp_add<0x112, 0xf>(x); // row_shr:2
+    x = dpp_add<0x114, 0xf>(x); // row_shr:4
+    x = dpp_add<0x118, 0xf>(x); // row_shr:8  -> lane 15 of each row holds the row sum
+    x = dpp_add<0x142, 0xa>(x); // row_bcast:15 into rows 1 and 3
+    x = dpp_add<0x143, 0xc>(x); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return x;
+}
 
 // ---------------------------------------------------------------------------
 // Pframeforce.cpp:21-94 CalculateNbodyPotential (+ Force.cpp:124-159 smoothing)
@@ -728,7 +749,7 @@ template <bool ROWU> __global__ void k_visc_fused(const Dev P)
 #define MARCH_LO 3
 
 template <int AV> // 0: none, 1: TW, 2: SN
-__global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk)
+__global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -912,6 +933,11 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                     P.vrad_b[IDX(k, j)] = vr3;
                     if (k < nr)
                         P.vazi_b[IDX(k, j)] = va3;
+                }
+                if (ring_sums && k < nr) { // this segment's share of sum_j v_phi(k, j) for the transport's <v_phi>
+                    const double part = wave_sum(store_lane ? va3 : 0.0);
+                    if (lane == 63)
+                        P.ring_part[k * P.ring_pstride + seg] = part;
                 }
             }
         }
@@ -1267,7 +1293,8 @@ __global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, 
                        (i == P.nr - 1 && P.is_last && P.bc_vaz[1] != FCPT_BC_NONE) ||
                        (!P.is_first && i < FCPT_OVERLAP) || (!P.is_last && i >= P.nr - FCPT_OVERLAP);
     double acc = 0.0;
-    if (part && !ghost) {
+    // (the CFL's partial sums are those of k_transport_fused: not valid when it gave up)
+    if (part && !ghost && !(with_shift == 0 && *P.shift_jump)) {
         for (int n = lane; n < nparts; n += 64)
             acc += part[i * pstride + n];
     } else {
@@ -2007,7 +2034,7 @@ __device__ __forceinline__ double damp_apply(double X, int type, double ef, cons
 }
 
 template <int C, bool ADI, bool DAMP, int LIM>
-__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows)
+__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int ring_sums)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     constexpr int LO = TfHalo<C>::lo, HI = TfHalo<C>::hi;
@@ -2284,6 +2311,15 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                 }
                 out_on = true;
                 out_pair = pair_valid && __builtin_amdgcn_ballot_w64(jout[C - 1] != jout[0] + 1) == 0;
+                if (ring_sums) { // this tile's share of sum_j v_phi(i, j) for the CFL's <v_phi>
+                    double part = 0.0;
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        part += valid[c] ? o_va[c] : 0.0;
+                    part = wave_sum(part);
+                    if (lane == 63)
+                        W.cfl_ring_part[i * W.ring_pstride + tile] = part;
+                }
             }
             ns_prev = ns;
 #pragma unroll
@@ -2620,16 +2656,19 @@ int launch_source_march(const Dev &P, hipStream_t st)
     if (const char *e = getenv("FCPT_SOURCE_ROWS")) // tuning knob
         rows = atoi(e) > 0 ? atoi(e) : rows;
     const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
+    int ring_sums = 0; // per-segment ring sums of v_phi for the transport's k_ring_mean (off: see launch_transport)
+    if (const char *e = getenv("FCPT_RING_PARTS"))
+        ring_sums = e[0] == '1' && segs <= P.ring_pstride;
     const int chunks = (P.nr + 1 + rows - 1) / rows;
     const int waves = segs * chunks;
     const dim3 grid((waves + 3) / 4), block(256);
     if (P.art_visc == FCPT_ARTVISC_TW)
-        KLAUNCH(KID_SOURCE_MARCH, k_source_march<1>, grid, block, P, segs, rows);
+        KLAUNCH(KID_SOURCE_MARCH, k_source_march<1>, grid, block, P, segs, rows, ring_sums);
     else if (P.art_visc == FCPT_ARTVISC_SN)
-        KLAUNCH(KID_SOURCE_MARCH, k_source_march<2>, grid, block, P, segs, rows);
+        KLAUNCH(KID_SOURCE_MARCH, k_source_march<2>, grid, block, P, segs, rows, ring_sums);
     else
-        KLAUNCH(KID_SOURCE_MARCH, k_source_march<0>, grid, block, P, segs, rows);
-    return segs;
+        KLAUNCH(KID_SOURCE_MARCH, k_source_march<0>, grid, block, P, segs, rows, ring_sums);
+    return ring_sums ? segs : -segs; // < 0: marched, but no ring sums
 }
 void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_FUSED, k_visc_fused, P.nr + 1, P); }
 void launch_substep3_after_fused(const Dev &P, hipStream_t st)
@@ -2739,7 +2778,7 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     // Transport, TransportEuler.cpp:112-136
-    TransportResult res = {0, W.sigma, W.energy, W.vrad, W.vazi};
+    TransportResult res = {0, 0, W.sigma, W.energy, W.vrad, W.vazi};
     // ---- everything in one kernel (tiled rings only) ------------------------------------------
     int CF = P.nphi >= 256 ? 1 : 0; // 1 cell per lane: 3 waves per SIMD (2 cells: 284 VGPRs, 1 wave)
     if (const char *e = getenv("FCPT_TRANSPORT_FUSED")) { // 0: off, 1 / 2: cells per lane
@@ -2760,11 +2799,17 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         const int tiles = (P.nphi + tstride - 1) / tstride;
         const int chunks = (P.nr + rows - 1) / rows;
         const dim3 grid((chunks * tiles + 3) / 4), block(256);
+        // per-tile ring sums of the new v_phi for the next CFL: measured 3 us slower per step than
+        // letting k_ring_mean re-read the grid (the reduction sits on the marching critical path): off
+        int ring_sums = 0;
+        if (const char *e = getenv("FCPT_RING_PARTS"))
+            ring_sums = e[0] == '1' && tiles <= P.ring_pstride;
+        res.cfl_parts = ring_sums ? tiles : 0;
 #define TFK(CC, AA, DD)                                                                                             \
     if (P.limiter == FCPT_LIMITER_MC)                                                                                \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows); \
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, ring_sums); \
     else                                                                                                             \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows)
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, ring_sums)
 #define TFC(CC)               \
     if (P.adiabatic) {        \
         if (W.damp_in_step)   \
