@@ -44,6 +44,7 @@ class SlabSet:
                  allreduce_min: Optional[Callable[[float], float]] = None):
         self.ctxs: List[B.Context] = list(ctxs)
         self._allreduce_min = allreduce_min or (lambda x: x)
+        self.dt_scale = 1.0  # tests: step with a multiple of the CFL time step
 
     # -- communication --------------------------------------------------------
     def global_cfl(self) -> float:
@@ -83,6 +84,7 @@ class SlabSet:
     def step(self, snap: bool = False) -> float:
         dt = self.calculate_timestep()
         step_dt = self.ctxs[0].snap_to_monitor(dt) if snap else dt
+        step_dt *= self.dt_scale
         for c in self.ctxs:
             c.step(step_dt)
         self.exchange_local()

@@ -193,3 +193,60 @@ def test_boundary_damping_grid_variants(product, oracle, case):
     da = d.copy()
     da.eos = B.EOS_IDEAL
     _check(run_pair(product, oracle, da, 12), ("sigma", "vrad", "vazi", "energy"))
+
+
+FUSED_CASES = ["iso_tw", "iso_sn_mc", "iso_noav_constnu_standard", "adiabatic", "adiabatic_sn", "outflow_zeroshear",
+               "reference_bc_damp_zero", "no_damping", "arithmetic_odd", "three_slabs", "leapfrog", "two_cells_per_lane"]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_transport_variants(product, oracle, case, monkeypatch):
+    """k_transport_fused (radial + azimuthal transport + velocities in one marching kernel) takes
+    rings of Nphi >= 256: every physics / boundary / grid variant of the path at such sizes."""
+    d = setups.planet_disk(product, 44, 320, adiabatic=case.startswith("adiabatic"))
+    fields = ("sigma", "vrad", "vazi") + (("energy",) if case.startswith("adiabatic") else ())
+    kw = {}
+    if case == "iso_sn_mc":
+        d.artificial_viscosity, d.flux_limiter = B.ARTVISC_SN, B.LIMITER_MC
+    elif case == "iso_noav_constnu_standard":
+        d.artificial_viscosity, d.fast_transport = B.ARTVISC_NONE, 0
+        d.viscous_alpha, d.constant_viscosity = 0.0, 1e-5
+    elif case == "adiabatic_sn":
+        d.artificial_viscosity = B.ARTVISC_SN
+    elif case == "outflow_zeroshear":
+        for s in (0, 1):
+            d.bc_vrad[s], d.bc_vaz[s] = B.BC_OUTFLOW, B.BC_ZEROSHEAR
+    elif case == "reference_bc_damp_zero":
+        for s in (0, 1):
+            d.bc_sigma[s] = d.bc_energy[s] = d.bc_vrad[s] = d.bc_vaz[s] = B.BC_REFERENCE
+        for arr in (d.damp_vrad, d.damp_sigma):
+            arr[0] = arr[1] = B.DAMP_ZERO
+    elif case == "no_damping":
+        d.damping = 0
+    elif case == "arithmetic_odd":
+        d.radial_spacing = B.SPACING_ARITHMETIC
+        d.nr_global, d.nphi = 37, 263
+    elif case == "three_slabs":
+        d.nr_global = 60
+        kw["nslabs"] = (3, 1)
+    elif case == "leapfrog":
+        d.integrator = B.INTEGRATOR_LEAPFROG
+    elif case == "two_cells_per_lane":
+        monkeypatch.setenv("FCPT_TRANSPORT_FUSED", "2")
+    _check(run_pair(product, oracle, d, 25, bodies=setups.jupiter_bodies(d), **kw), fields)
+
+
+def test_transport_beyond_shear_limit_falls_back(product, oracle, monkeypatch):
+    """k_transport_fused couples rings i-1 and i through one lane shift, which covers
+    |Nshift[i] - Nshift[i-1]| <= 1 (every dt inside the FARGO shear limit, cfl.cpp:207-220).  A step
+    of 4x the CFL time step breaks that: the kernel must give up and the unfused kernels queued
+    behind it must produce the step -- and without them the result must be wrong, which shows the
+    situation did occur."""
+    d = setups.planet_disk(product, 48, 512)
+    d.damping = 0
+    d.first_dt = 1.0  # no 1.1x ramp: the first step already runs at the CFL limit
+    bodies = setups.jupiter_bodies(d)
+    _check(run_pair(product, oracle, d, 3, bodies=bodies, dt_scale=4.0), ("sigma", "vrad", "vazi"))
+    monkeypatch.setenv("FCPT_TRANSPORT_FALLBACK", "0")
+    (a, _), (b, _) = run_pair(product, oracle, d, 3, bodies=bodies, dt_scale=4.0)
+    assert rel_err(a["vrad"], b["vrad"]) > 1e-6 or not np.isfinite(a["vrad"]).all()

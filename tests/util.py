@@ -28,7 +28,7 @@ def perturb(fields, d, amp=1e-3):
     return sigma, vrad, vazi, energy
 
 
-def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=(1, 1)):
+def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=(1, 1), dt_scale=1.0):
     """Advance the same initial state `nsteps` with two libraries; returns the two global
     states and the two dt histories."""
     outs = []
@@ -50,6 +50,7 @@ def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=
             sub = tuple(np.ascontiguousarray(x) for x in sub)
             ctxs.append(driver.make_context(L, dd, fields=sub, radii=radii, bodies=bodies))
         S = driver.SlabSet(ctxs)
+        S.dt_scale = dt_scale
         S.prepare()
         dts = S.run(nsteps, snap=snap)
         outs.append((S.gather(), dts))
