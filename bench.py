@@ -166,15 +166,16 @@ def main():
         slab_cells = ctx.nr * args.nphi
         algo_bytes = ALGO_DOUBLES.get(dominant, (0, 0))[adi] * 8 * slab_cells
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        traffic = valu_busy = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("workload") == f"{args.nr}x{args.nphi}":
                     traffic = rec.get("hbm_bytes_per_launch", {}).get(dominant)
+                    valu_busy = rec.get("valu_busy", {}).get(dominant)
             except Exception:
-                traffic = None
+                traffic = valu_busy = None
         out = {
             "metric": "cell-updates/s on Nr x Nphi polar grid", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,7 +191,12 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": dom_ms, "launches": dom[1],
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "step_frac": value * STEP_BYTES[adi] / (HBM_PEAK_GBS * 1e9 * world)},
+                         # the whole step against SURVEY.md 8(d)'s 256|320 B per cell-update
+                         "step_frac": value * STEP_BYTES[adi] / (HBM_PEAK_GBS * 1e9 * world),
+                         # busy fraction of the FP64 vector ALUs in this kernel (PMC, profiles/pmc_latest.json):
+                         # k_transport_fused moves 48 B per cell instead of the model's 216 B and is bound by
+                         # the vector pipeline, not by HBM
+                         "valu_busy": valu_busy},
             "kernel_ms_per_step": {k: v[0] / cal for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]},
         }
         if world == 1 and not args.no_cpu_baseline:

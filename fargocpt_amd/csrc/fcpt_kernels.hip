@@ -1275,7 +1275,7 @@ template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(c
 }
 
 // compute_average_azimuthal_velocity (:174-189) + ComputeConstantResidual (:207-236):
-// one wavefront per ring (4 rings per block), 16-byte loads with 8 in flight per lane, DPP-free
+// one wavefront per ring (4 rings per block), 16-byte loads with 16 in flight per lane, a
 // butterfly for the ring sum; the per-ring scalars of the epilogue are fetched up front so the
 // last lane-0 instructions do not queue behind three dependent memory round trips.
 __global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, const double *part, int nparts, int pstride)
@@ -1302,13 +1302,13 @@ __global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, 
         const int npair = P.nphi >> 1;
         double acc2 = 0.0;
         int n = lane;
-        for (; n + 7 * 64 < npair; n += 8 * 64) {
-            D2 v[8];
+        for (; n + 15 * 64 < npair; n += 16 * 64) {
+            D2 v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 v[u] = *(const D2 *)(row + 2 * (n + u * 64));
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 acc += v[u].x;
                 acc2 += v[u].y;
             }
