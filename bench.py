@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nr", type=int, default=NR_PER_GPU, help="rings per GPU")
     ap.add_argument("--nphi", type=int, default=NPHI)
+    ap.add_argument("--eos", choices=["isothermal", "ideal"], default="isothermal",
+                    help="ideal: BASELINE config 3 physics (energy equation, viscous heating) on the same grid")
     args = ap.parse_args()
 
     os.environ.setdefault("OMP_NUM_THREADS", str(affinity_threads()))
@@ -87,7 +89,7 @@ def main():
 
     lib = fargocpt_amd.load()
     nr_global = args.nr * world
-    d = setups.planet_disk(lib, nr_global, args.nphi)
+    d = setups.planet_disk(lib, nr_global, args.nphi, adiabatic=args.eos == "ideal")
     if world > 1:
         # weak scaling: keep dr/r of the 1-GPU grid, extend the disk outward
         d.rmax = d.rmin * (2.5 / 0.4) ** world
@@ -181,7 +183,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{nr_global}x{args.nphi} locally-isothermal disk + 1 Jupiter-mass planet "
+            "config": {"workload": f"{nr_global}x{args.nphi} {'ideal-gas' if adi else 'locally-isothermal'} disk + 1 Jupiter-mass planet "
                                    "(examples/config.yml physics: alpha=1e-3, TW artificial viscosity, "
                                    "reflecting BC + damping, FARGO transport, Euler), "
                                    f"{args.nr} rings per GPU",

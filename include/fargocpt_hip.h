@@ -261,7 +261,9 @@ int fcpt_set_clock(fcpt_ctx *ctx, const fcpt_clock *in);
  * Synchronous with respect to the context's stream. */
 int fcpt_upload(fcpt_ctx *ctx, int32_t field, const double *host);
 int fcpt_download(fcpt_ctx *ctx, int32_t field, double *host);
-/* Device address and element count of a grid, for zero-copy callers. */
+/* Device address and element count of a grid, for zero-copy callers.  The transport is out of place:
+ * the addresses of SIGMA, ENERGY, VRAD and VAZI may change in fcpt_step / fcpt_step_device /
+ * fcpt_run_steps -- query again after a step. */
 int fcpt_device_ptr(fcpt_ctx *ctx, int32_t field, void **dptr, uint64_t *count);
 
 /* Positions, masses and cubic smoothing radii of the N-body objects for the
