@@ -38,6 +38,7 @@ struct fcpt_ctx {
     bool profiling = false;
     bool fused_source = true;
     int src_parts = 0; // segments of ring sums left by the last k_source_march
+    bool kick_energy_b = false; // the last kick left the energy in energy_b (marching source step, ideal EOS)
     bool march_source = true;
     bool stepped = false; // fcpt_step ran since the last fcpt_post
     bool pressure_valid = false;
@@ -183,10 +184,14 @@ int read_clock(fcpt_ctx *c, DevClock *out)
 
 // isothermal pressure is Sigma c_s^2 with c_s fixed per ring: the marching source kernel forms
 // it in registers, so the grid is only materialised for callers that ask for it
+// (ideal EOS with the marching source step: the same holds for T, c_s, H and nu)
 void ensure_pressure(fcpt_ctx *c)
 {
     if (!c->pressure_valid) {
-        launch_pressure(c->P, c->stream);
+        if (c->P.adiabatic)
+            launch_derived(c->P, c->stream);
+        else
+            launch_pressure(c->P, c->stream);
         c->pressure_valid = true;
     }
 }
@@ -198,16 +203,17 @@ bool enqueue_kick(fcpt_ctx *c)
     const Dev &P = c->P;
     hipStream_t st = c->stream;
     if (c->fused_source) {
-        const int segs = c->march_source ? launch_source_march(P, st) : 0; // one pass: (v) -> (v_b)
+        const int segs = c->march_source ? launch_source_march(P, st) : 0; // one pass: (v[, e]) -> (v_b[, e_b])
         c->src_parts = segs > 0 ? segs : 0;
+        c->kick_energy_b = segs != 0 && P.adiabatic;
         if (!segs) {
             ensure_pressure(c);
             launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
             launch_recalculate_viscosity(P, st);
             launch_viscous_fused(P, st);         // (v) -> (v_b)
+            if (P.adiabatic)
+                launch_substep3_after_fused(P, st);
         }
-        if (P.adiabatic)
-            launch_substep3_after_fused(P, st);
         return true;
     }
     ensure_pressure(c);
@@ -261,6 +267,9 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt)
         Q.vrad = P.vrad_b;
         Q.vazi = P.vazi_b;
     }
+    if (c->kick_energy_b)
+        Q.energy = P.energy_b;
+    c->kick_energy_b = false;
     Q.src_ring_nparts = in_b ? c->src_parts : 0; // ring sums of v_phi left by k_source_march
     c->src_parts = 0;
     apply_boundary_view(c, Q, false);
@@ -287,12 +296,15 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt)
         launch_clock_scale_dt(P.clk, 2, 0.0, 0.5, st); // dt <- step/2
         enqueue_potential(c, true);
         c->pressure_valid = false; // compute_pressure(data), simulation.cpp:378
-        if (P.adiabatic)
+        if (P.adiabatic && !P.lazy_derived)
             ensure_pressure(c);
         if (enqueue_kick(c)) { // result in the *_b buffers: bring it home
             const size_t ns = (size_t)P.nr * P.nphi * sizeof(double), nv = (size_t)(P.nr + 1) * P.nphi * sizeof(double);
             (void)hipMemcpyAsync(P.vrad, P.vrad_b, nv, hipMemcpyDeviceToDevice, st);
             (void)hipMemcpyAsync(P.vazi, P.vazi_b, ns, hipMemcpyDeviceToDevice, st);
+            if (c->kick_energy_b)
+                (void)hipMemcpyAsync(P.energy, P.energy_b, ns, hipMemcpyDeviceToDevice, st);
+            c->kick_energy_b = false;
         }
         launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step, for the damping of the final boundary call
     }
@@ -304,7 +316,7 @@ void enqueue_post(fcpt_ctx *c)
     // the damping of the final boundary call was applied by k_velocities when damp_in_step
     apply_boundary_view(c, c->P, true, c->P.damp_in_step != 0 && c->stepped);
     c->stepped = false;
-    if (c->P.adiabatic) {
+    if (c->P.adiabatic && !c->P.lazy_derived) {
         launch_derived(c->P, c->stream);
         c->pressure_valid = true;
     } else {
@@ -416,6 +428,12 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         if (!rc) rc = dev_upload(c, &P.g_inv_dxtheta.p, t2);
         if (!rc) rc = dev_upload(c, &P.g_dr_invsurf.p, t3);
         if (!rc) rc = dev_upload(c, &P.g_r_omega.p, t4);
+        std::vector<double> t5(nr + 1, 0.0);
+        for (int i = 0; i < nr; ++i) {
+            const double rm = g.Rmed[i];
+            t5[i] = 1.0 / std::sqrt(d->G * d->hydro_center_mass / (rm * rm * rm));
+        }
+        if (!rc) rc = dev_upload(c, &P.g_inv_omk.p, t5);
         std::vector<RadRow> rt(nr + 2);
         for (int k = -1; k <= nr; ++k) {
             const bool open = k > 0 && k < nr;
@@ -476,6 +494,12 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
                 const double rDphi = g.Rmed[r] * g.dphi;
                 const double dx = nphi <= 16 ? std::min(Dr, rDphi) : std::max(Dr, rDphi);
                 R.lsq_b = C2 * (dx * dx);
+                R.rinf_b1 = g.Rinf[r + 1];
+                R.rinf_b0 = g.Rinf[r];
+                R.inv_drsuprb_b = g.InvDiffRsupRb[r];
+                const double rm = g.Rmed[r];
+                R.inv_omk_b = 1.0 / std::sqrt(d->G * d->hydro_center_mass / (rm * rm * rm));
+                R.inv_dxtheta_b = 1.0 / (g.dphi * rm);
             }
             {
                 const int r = m - 1;
@@ -531,7 +555,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
 #define AL(field, n) \
     if (!rc)         \
         rc = dev_alloc(c, &P.field, (n));
-    AL(sigma, ns) AL(vrad, nv) AL(vazi, ns) AL(energy, ns) AL(vrad_b, nv) AL(vazi_b, ns)
+    AL(sigma, ns) AL(vrad, nv) AL(vazi, ns) AL(energy, ns) AL(vrad_b, nv) AL(vazi_b, ns) AL(energy_b, ns)
     AL(pressure, ns) AL(soundspeed, ns) AL(scale_height, ns) AL(viscosity, ns) AL(temperature, ns)
     AL(potential, ns)
     AL(sigma0, ns) AL(vrad0, nv) AL(vazi0, ns) AL(energy0, ns)
@@ -700,6 +724,12 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         c->fused_source = e[0] != '0';
     if (const char *e = getenv("FCPT_MARCH_SOURCE"))
         c->march_source = e[0] != '0';
+    {
+        bool adi_march = c->P.adiabatic && c->fused_source && c->march_source && c->P.nphi >= 128;
+        if (const char *e = getenv("FCPT_MARCH_SOURCE_ADI"))
+            adi_march = adi_march && e[0] != '0';
+        c->P.lazy_derived = adi_march ? 1 : 0;
+    }
     *out = c;
     return FCPT_OK;
 }
@@ -803,7 +833,8 @@ int fcpt_download(fcpt_ctx *c, int32_t f, double *host)
         set_error("bad argument to fcpt_download");
         return FCPT_EINVAL;
     }
-    if (f == FCPT_F_PRESSURE)
+    if (f == FCPT_F_PRESSURE || (c->P.adiabatic && (f == FCPT_F_SOUNDSPEED || f == FCPT_F_SCALE_HEIGHT ||
+                                                     f == FCPT_F_VISCOSITY || f == FCPT_F_TEMPERATURE)))
         ensure_pressure(c);
     HIPCHK(hipMemcpyAsync(host, c->grid[f], grid_count(c, f) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -96,7 +96,8 @@ struct alignas(64) SrcRow {
     double inv_rmed_r, inv_rmed_rm1, idr_r, rinf_r, inv_rinf_r, nu_avg_r;
     // stage E, ring k = m-2
     double inv_rmed_k, two_inv_dra2_k, ra1sq_k, ra0sq_k, inv_rmsum_k, rmed_k, rmed_km1, idr_k;
-    double pad[5];
+    // energy equation, ring crow(m-1): Rinf[r+1], Rinf[r], InvDiffRsupRb[r], 1/Omega_K(Rmed[r]), 1/(dphi Rmed[r])
+    double rinf_b1, rinf_b0, inv_drsuprb_b, inv_omk_b, inv_dxtheta_b;
 };
 static_assert(sizeof(SrcRow) == 320, "SrcRow is five 64-byte scalar loads");
 struct alignas(64) ThetaRow { // ring i
@@ -128,9 +129,13 @@ struct Dev {
     CArr g_inv_dxt_src, g_inv_rsum, g_inv_drmed2, g_inv_dra2, g_inv_rmsum;
     //   g_dxtheta = dphi Rmed, g_inv_dxtheta = 1/(dphi Rmed), g_dr_invsurf = (Rsup-Rinf) InvSurf, g_r_omega = Rmed OmegaFrame
     CArr g_dxtheta, g_inv_dxtheta, g_dr_invsurf, g_r_omega;
+    CArr g_inv_omk;  // 1 / Omega_K(Rmed[i])
+    int lazy_derived; // ideal EOS + marching source step: c_s, H, nu, T, P are formed in registers where needed,
+                      // the grids are only materialised for callers that ask for them
     // state
     double *sigma, *vrad, *vazi, *energy;
     double *vrad_b, *vazi_b; // intermediate velocities of the fused source step
+    double *energy_b;        // energy after the marching source step (ideal EOS)
     // derived
     double *pressure, *soundspeed, *scale_height, *viscosity, *temperature, *potential;
     // reference (t = 0) copies
