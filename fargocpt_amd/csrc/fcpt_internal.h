@@ -177,6 +177,8 @@ struct Dev {
     int alpha_viscosity;
     double gamma, mu, Rgas, G, Mc, sigma_sb, c_light, aspect_ratio, flaring_index;
     double tmin, tmax, sigma_floor_abs, sigma_floor_rel, sigma0_val;
+    double emin_fac, emax_fac; // T_min|max / mu * R / (gamma - 1): energy floor / ceiling per unit Sigma
+    double b_fac;              // mu (gamma - 1) / R of SubStep3's alpha
     double alpha, nu_const, radial_viscosity_factor, art_visc_factor, heating_viscous_factor;
     double omega_frame, thickness_smoothing, cfl, cfl_max_var, heating_cooling_cfl_limit;
     double monitor_timestep;

@@ -151,8 +151,8 @@ template <bool ROWU> __global__ void k_potential(const Dev P)
     const double y = P.Rmed[i] * P.sinphi[j];
     double H;
     if (P.adiabatic && P.lazy_derived) { // k_adi_cs_h in registers
-        const double cs = sqrt(P.gamma * (P.gamma - 1.0) * P.energy[IDX(i, j)] / P.sigma[IDX(i, j)]);
-        H = cs / (sqrt(P.gamma)) * P.g_inv_omk[i];
+        const double cs = sqrt(P.gamma * (P.gamma - 1.0) * P.energy[IDX(i, j)] * fast_rcp(P.sigma[IDX(i, j)]));
+        H = cs * (1.0 / sqrt(P.gamma)) * P.g_inv_omk[i];
     } else {
         H = P.scale_height[IDX(i, j)];
     }
@@ -316,6 +316,18 @@ __device__ __forceinline__ double clamp_energy(const Dev &P, double e, double rh
 {
     const double e_min = P.tmin * rho / P.mu * P.Rgas / (P.gamma - 1.0);
     const double e_max = P.tmax * rho / P.mu * P.Rgas / (P.gamma - 1.0);
+    if (!(e > e_min))
+        e = e_min;
+    if (!(e < e_max))
+        e = e_max;
+    return e;
+}
+// the same with the per-unit-Sigma bounds formed once on the host (the quotient chain above costs
+// four IEEE divisions per cell; the bounds only matter where they bind, to 1 ulp)
+__device__ __forceinline__ double clamp_energy_fast(const Dev &P, double e, double rho)
+{
+    const double e_min = P.emin_fac * rho;
+    const double e_max = P.emax_fac * rho;
     if (!(e > e_min))
         e = e_min;
     if (!(e < e_max))
@@ -983,7 +995,7 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     const double dt = P.clk->dt;
     const double C2 = P.art_visc_factor * P.art_visc_factor;
     const double gm1 = P.gamma - 1.0;
-    const double sqrt_gamma = sqrt(P.gamma);
+    const double inv_sqrt_gamma = 1.0 / sqrt(P.gamma);
     const bool dissipate = P.art_visc_dissipation != 0;
 
 #define NEXT(x) lane_next(x) /* value of cell j+1 */
@@ -1098,11 +1110,11 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
                     e = e - dt * qr_1 * dv_r * R.inv_drsup_b - dt * qp_1 * dv_phi * R.inv_dxtheta_b;
             }
             if (dissipate) // update_with_artificial_viscosity ends with the temperature floor/ceiling
-                e = clamp_energy(P, e, S_1);
+                e = clamp_energy_fast(P, e, S_1);
             e2_1 = e;
             // V0: recalculate_viscosity on ring m-1
-            const double cs = sqrt(P.gamma * gm1 * e / S_1);
-            H_1 = cs / sqrt_gamma * R.inv_omk_b;
+            const double cs = sqrt(P.gamma * gm1 * e * fast_rcp(S_1));
+            H_1 = cs * inv_sqrt_gamma * R.inv_omk_b;
             nu_1 = P.alpha_viscosity ? P.alpha * H_1 * cs : P.nu_const;
             nup_1 = PREV(nu_1);
         }
@@ -1183,15 +1195,15 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
                 if (k < nr) {
                     if (P.heating_viscous && row_va && nu_2 != 0.0) { // viscous_heating
                         const double tau_r_phi = 0.25 * (trp_2 + trp_1 + trp_n + trp_1n);
-                        double q = 1.0 / (2.0 * nu_2 * S_2) * (trr_2 * trr_2 + 2 * (tau_r_phi * tau_r_phi) + tpp_2 * tpp_2);
+                        double q = fast_rcp(2.0 * nu_2 * S_2) * (trr_2 * trr_2 + 2 * (tau_r_phi * tau_r_phi) + tpp_2 * tpp_2);
                         q += (2.0 / 9.0) * nu_2 * S_2 * (divv_2 * divv_2);
                         q *= P.heating_viscous_factor;
                         qplus += q;
                     }
                     if (row_va) { // SubStep3, rows [1, Nr-1)
-                        const double alpha = substep3_alpha(P, H_2, S_2, e);
-                        qplus = qplus / alpha;
-                        qminus = qminus / alpha;
+                        const double bb = P.b_fac * fast_rcp(S_2), b2 = bb * bb; // substep3_alpha
+                        const double alpha = 1.0 + 2.0 * H_2 * 4.0 * P.sigma_sb / P.c_light * (b2 * b2) * (e * e * e);
+                        qplus = qplus * fast_rcp(alpha);
                         double energy_new = e + dt * (qplus - qminus);
                         const double SigmaFloor = 10.0 * P.sigma0_val * P.sigma_floor_rel;
                         if (S_2 < SigmaFloor) {
@@ -1200,7 +1212,7 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
                         }
                         e = energy_new;
                     }
-                    e = clamp_energy(P, e, S_2); // SetTemperatureFloorCeilValues
+                    e = clamp_energy_fast(P, e, S_2); // SetTemperatureFloorCeilValues
                 }
                 if (store_lane) {
                     P.vrad_b[IDX(k, j)] = vr3;
@@ -2569,7 +2581,7 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                         vr = (rp[c] + Q[1][c]) * fast_rcp(sp[c] + S[c]);
                     double va = (lpm + Q[3][c]) * fast_rcp(sm + S[c]) * invr - romega;
                     double sf = S[c] < P.sigma_floor_abs ? P.sigma_floor_abs : S[c];
-                    double e = ADI ? clamp_energy(P, E[c], sf) : 0.0;
+                    double e = ADI ? clamp_energy_fast(P, E[c], sf) : 0.0;
                     const int g = row + jout[c];
                     if (DAMP) {
                         vr = damp_apply(vr, di.tvr, si.ev, W.vrad0, g, 0.0);
@@ -2673,6 +2685,8 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
         const int r1 = r0 + CFL_ROWS < P.active_size ? r0 + CFL_ROWS : P.active_size;
         const double lf = P.leapfrog ? 0.6 : 1.0;
         const double C2 = P.art_visc_factor * P.art_visc_factor;
+        const double gg1 = P.gamma * (P.gamma - 1.0), inv_sqrt_gamma = 1.0 / sqrt(P.gamma);
+        const double inv_limit = 1.0 / P.heating_cooling_cfl_limit;
         double vr0 = P.vrad[IDX(r0, j)];
         for (int i = r0; i < r1; ++i) {
             const double vr1 = P.vrad[IDX(i + 1, j)];
@@ -2685,8 +2699,8 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
             // isothermal: c_s and the alpha viscosity are per-ring constants (set once at init)
             double cs, nu;
             if (P.adiabatic && P.lazy_derived) { // k_adi_cs_h + k_viscosity in registers
-                cs = sqrt(P.gamma * (P.gamma - 1.0) * P.energy[IDX(i, j)] / P.sigma[IDX(i, j)]);
-                const double H = cs / (sqrt(P.gamma)) * P.g_inv_omk[i];
+                cs = sqrt(gg1 * P.energy[IDX(i, j)] * fast_rcp(P.sigma[IDX(i, j)]));
+                const double H = cs * inv_sqrt_gamma * P.g_inv_omk[i];
                 nu = P.alpha_viscosity ? P.alpha * H * cs : P.nu_const;
             } else {
                 cs = P.adiabatic ? P.soundspeed[IDX(i, j)] : P.cs_ring[i];
@@ -2711,8 +2725,10 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
             const double invdt5 = 4.0 * nu * (inv_cell * inv_cell) * lf;
             double invdt6 = 0.0;
             if (P.adiabatic) {
-                const double inv_limit = 1.0 / P.heating_cooling_cfl_limit;
-                invdt6 = inv_limit * fabs((P.qplus[IDX(i, j)] - P.qminus[IDX(i, j)]) / P.energy[IDX(i, j)]) * lf;
+                if (P.lazy_derived)
+                    invdt6 = inv_limit * fabs((P.qplus[IDX(i, j)] - P.qminus[IDX(i, j)]) * fast_rcp(P.energy[IDX(i, j)])) * lf;
+                else
+                    invdt6 = inv_limit * fabs((P.qplus[IDX(i, j)] - P.qminus[IDX(i, j)]) / P.energy[IDX(i, j)]) * lf;
             }
             s = dmax(s, invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 + invdt5 * invdt5 +
                             invdt6 * invdt6);
