@@ -32,6 +32,9 @@ class DistributedSlab:
         self.s_in, self.r_in = (mk(), mk()) if self.has_inner else (None, None)
         self.s_out, self.r_out = (mk(), mk()) if self.has_outer else (None, None)
         self._dt = torch.zeros(1, dtype=torch.float64, device=self.device)
+        # gloo has no send/recv of device tensors: GPU slabs on a gloo group (tests: several ranks on
+        # the one GPU of a box) stage the ghost rings through host tensors; RCCL sends them in place
+        self.stage_host = self.on_gpu and ready and dist.get_backend() == "gloo"
         if self.on_gpu:
             ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -55,13 +58,24 @@ class DistributedSlab:
         if self.world == 1:
             return
         self.ctx.exchange_pack(self._arg(self.s_in), self._arg(self.s_out))
+        if self.stage_host:
+            self.ctx.synchronize()
+            s_in, s_out = (t.cpu() if t is not None else None for t in (self.s_in, self.s_out))
+            r_in, r_out = (torch.empty_like(t) if t is not None else None for t in (s_in, s_out))
+        else:
+            s_in, s_out, r_in, r_out = self.s_in, self.s_out, self.r_in, self.r_out
         ops = []
         if self.has_inner:
-            ops += [dist.P2POp(dist.isend, self.s_in, self.rank - 1), dist.P2POp(dist.irecv, self.r_in, self.rank - 1)]
+            ops += [dist.P2POp(dist.isend, s_in, self.rank - 1), dist.P2POp(dist.irecv, r_in, self.rank - 1)]
         if self.has_outer:
-            ops += [dist.P2POp(dist.isend, self.s_out, self.rank + 1), dist.P2POp(dist.irecv, self.r_out, self.rank + 1)]
+            ops += [dist.P2POp(dist.isend, s_out, self.rank + 1), dist.P2POp(dist.irecv, r_out, self.rank + 1)]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+        if self.stage_host:
+            if self.has_inner:
+                self.r_in.copy_(r_in)
+            if self.has_outer:
+                self.r_out.copy_(r_out)
         self.ctx.exchange_unpack(self._arg(self.r_in), self._arg(self.r_out))
 
     def step_async(self):
