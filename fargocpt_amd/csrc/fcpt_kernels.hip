@@ -2745,6 +2745,116 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
     if (tid == 0)
         part[blockIdx.y * gridDim.x + blockIdx.x] = dmax(dmax(s_w[0], s_w[1]), dmax(s_w[2], s_w[3]));
 }
+// Ring mean and per-cell limits in one pass: a block owns a ring, keeps its v_phi in registers
+// (CFL_MAXP pairs per thread), sums them (<v_phi>, cfl.cpp:196-205), then evaluates the cells of
+// the ring against that mean (:222-330) -- v_phi is read once instead of once by k_ring_mean and
+// once by k_cfl_cells.  One partial maximum per ring.
+#define CFL_MAXP 8
+template <bool ADI> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part)
+{
+    const int i = blockIdx.x;
+    const int nphi = P.nphi, npair = nphi >> 1;
+    const int t = threadIdx.x;
+    const size_t row = (size_t)i * nphi;
+    D2 va[CFL_MAXP];
+    double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+    for (int n = 0; n < CFL_MAXP; ++n) {
+        const int p = t + n * 256;
+        va[n] = D2{0.0, 0.0};
+        if (p < npair)
+            va[n] = *(const D2 *)(P.vazi + row + 2 * p);
+    }
+#pragma unroll
+    for (int n = 0; n < CFL_MAXP; ++n) {
+        acc += va[n].x;
+        acc2 += va[n].y;
+    }
+    acc += acc2;
+    for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_down(acc, off, 64);
+    __shared__ double s_w[4], s_m[4];
+    if ((t & 63) == 0)
+        s_w[t >> 6] = acc;
+    __syncthreads();
+    const double mean = ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) / (double)nphi;
+    if (t == 0)
+        P.vmean[i] = mean;
+    double s = 0.0;
+    if (i >= P.first_active && i < P.active_size) {
+        const double lf = P.leapfrog ? 0.6 : 1.0;
+        const double C2 = P.art_visc_factor * P.art_visc_factor;
+        const double inv_dxr = P.InvDiffRsup[i];         // 1 / (Rsup - Rinf)
+        const double inv_rmed = P.InvRmed[i];
+        const double inv_dxa = inv_rmed * P.invdphi;     // 1 / (Rmed dphi)
+        const double inv_cell = dmax(inv_dxr, inv_dxa);  // 1 / min(dxRadial, dxAzimuthal)
+        const double gg1 = P.gamma * (P.gamma - 1.0), inv_sqrt_gamma = 1.0 / sqrt(P.gamma);
+        const double inv_limit = 1.0 / P.heating_cooling_cfl_limit;
+        const double inv_omk = ADI ? P.g_inv_omk[i] : 0.0;
+        const double cs_iso = ADI ? 0.0 : P.cs_ring[i];
+        const double nu_iso = ADI ? 0.0 : (P.alpha_viscosity ? P.nu_ring[i] : P.nu_const);
+        const double sub = P.fast_transport ? mean : 0.0;
+#pragma unroll
+        for (int n = 0; n < CFL_MAXP; ++n) {
+            const int p = t + n * 256;
+            if (p < npair) {
+                const int j = 2 * p;
+                const D2 r0 = *(const D2 *)(P.vrad + row + j), r1 = *(const D2 *)(P.vrad + row + nphi + j);
+                const double van1 = P.vazi[row + (j + 2 >= nphi ? 0 : j + 2)]; // v_phi of cell j+2
+                D2 e2 = {0.0, 0.0}, s2 = {1.0, 1.0}, qp = {0.0, 0.0}, qm = {0.0, 0.0};
+                if (ADI) {
+                    e2 = *(const D2 *)(P.energy + row + j);
+                    s2 = *(const D2 *)(P.sigma + row + j);
+                    qp = *(const D2 *)(P.qplus + row + j);
+                    qm = *(const D2 *)(P.qminus + row + j);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const double vr0 = c ? r0.y : r0.x, vr1 = c ? r1.y : r1.x;
+                    const double v = c ? va[n].y : va[n].x, van = c ? van1 : va[n].y;
+                    double cs = cs_iso, nu = nu_iso;
+                    if (ADI) { // k_adi_cs_h + k_viscosity in registers
+                        const double e = c ? e2.y : e2.x, sg = c ? s2.y : s2.x;
+                        cs = sqrt(gg1 * e * fast_rcp(sg));
+                        const double H = cs * inv_sqrt_gamma * inv_omk;
+                        nu = P.alpha_viscosity ? P.alpha * H * cs : P.nu_const;
+                    }
+                    const double invdt1 = cs * inv_cell;
+                    const double invdt2 = vr0 * inv_dxr;
+                    const double invdt3 = (v - sub) * inv_dxa;
+                    double invdt4;
+                    if (P.art_visc == FCPT_ARTVISC_SN) {
+                        double dvRadial = vr1 - vr0;
+                        double dvAzimuthal = van - v;
+                        dvRadial = dvRadial > 0.0 ? 0.0 : -dvRadial;
+                        dvAzimuthal = dvAzimuthal > 0.0 ? 0.0 : -dvAzimuthal;
+                        invdt4 = 4.0 * C2 * dmax(dvRadial * inv_dxr, dvAzimuthal * inv_dxa) * lf;
+                    } else { // the TW formula is also used for ArtificialViscosity: None (cfl.cpp:292)
+                        const double eps_rr = (vr1 - vr0) * inv_dxr;
+                        const double eps_pp = inv_rmed * ((van - v) * P.invdphi + 0.5 * (vr1 + vr0));
+                        const double mdiv_V = -dmin(eps_rr + eps_pp, 0.0);
+                        invdt4 = 4.0 * C2 * mdiv_V * lf;
+                    }
+                    const double invdt5 = 4.0 * nu * (inv_cell * inv_cell) * lf;
+                    double invdt6 = 0.0;
+                    if (ADI) {
+                        const double e = c ? e2.y : e2.x;
+                        invdt6 = inv_limit * fabs(((c ? qp.y : qp.x) - (c ? qm.y : qm.x)) * fast_rcp(e)) * lf;
+                    }
+                    s = dmax(s, invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 +
+                                    invdt5 * invdt5 + invdt6 * invdt6);
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        s = dmax(s, __shfl_down(s, off, 64));
+    if ((t & 63) == 0)
+        s_m[t >> 6] = s;
+    __syncthreads();
+    if (t == 0)
+        part[i] = dmax(dmax(s_m[0], s_m[1]), dmax(s_m[2], s_m[3]));
+}
 __global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *part, int nparts, int apply_policy)
 {
     double smax = 0.0;
@@ -3230,6 +3340,20 @@ void launch_temperature(const Dev &P, hipStream_t st) { LAUNCH2D(KID_TEMPERATURE
 
 void launch_cfl(const Dev &P, int apply_policy, int use_part, hipStream_t st)
 {
+    // one block per ring: mean and cells in one pass (even Nphi up to 512 * CFL_MAXP; the isothermal
+    // viscosity and sound speed per ring, or the lazily derived ones of the ideal EOS)
+    bool rings = (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 512 * CFL_MAXP && (!P.adiabatic || P.lazy_derived) &&
+                 !use_part;
+    if (const char *e = getenv("FCPT_CFL_RINGS"))
+        rings = rings && e[0] != '0';
+    if (rings) {
+        if (P.adiabatic)
+            KLAUNCH(KID_CFL_CELLS, k_cfl_rings<true>, dim3(P.nr), dim3(256), P, P.cfl_part);
+        else
+            KLAUNCH(KID_CFL_CELLS, k_cfl_rings<false>, dim3(P.nr), dim3(256), P, P.cfl_part);
+        KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
+        return;
+    }
     KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 0,
             use_part ? (const double *)P.cfl_ring_part : (const double *)nullptr, P.cfl_ring_nparts, P.ring_pstride);
     const int nrows = P.active_size - P.first_active;
