@@ -1510,13 +1510,11 @@ __device__ __forceinline__ RadialFlux radial_flux(const Dev &P, int k, double v,
     f.e = P.adiabatic ? g * star_radial(P, geo, v, dt, a.e, b.e, c.e, d.e) * rho * v : 0.0;
     return f;
 }
-template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(const Dev P, const int *only_if)
+template <bool ROWU> __device__ __forceinline__ void transport_radial_block(const Dev &P, int vb, int gx, int nvb)
 {
-    if (only_if && !*only_if) // fallback behind k_transport_fused: runs only when that kernel gave up
-        return;
-    const int lb = xcd_block(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int j = (lb % gridDim.x) * blockDim.x + threadIdx.x;
-    const int r0_ = ((lb / gridDim.x) * blockDim.y + threadIdx.y) * RADIAL_ROWS;
+    const int lb = xcd_block(vb, nvb);
+    const int j = (lb % gx) * blockDim.x + threadIdx.x;
+    const int r0_ = ((lb / gx) * blockDim.y + threadIdx.y) * RADIAL_ROWS;
     if (j >= P.nphi || r0_ >= P.nr)
         return;
     const int r0 = ROWU ? __builtin_amdgcn_readfirstlane(r0_) : r0_;
@@ -1556,6 +1554,18 @@ template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(c
         v2 = v3; v3 = v4; v4 = v5; v5 = v6;
         fin = fout;
     }
+}
+
+// The kernel proper walks gx * gy virtual blocks with a grid stride: launched with one block per
+// virtual block in normal use, and with a small grid as the in-stream fallback of
+// k_transport_fused (only_if: runs only when that kernel gave up; an idle fallback then costs a
+// few hundred blocks that return at once, not thousands).
+template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(const Dev P, const int *only_if, int gx, int gy)
+{
+    if (only_if && !*only_if)
+        return;
+    for (int vb = blockIdx.x; vb < gx * gy; vb += gridDim.x)
+        transport_radial_block<ROWU>(P, vb, gx, gx * gy);
 }
 
 // compute_average_azimuthal_velocity (:174-189) + ComputeConstantResidual (:207-236):
@@ -2094,15 +2104,13 @@ __device__ __forceinline__ void theta_pass(int lim, int lsrc_l, int lsrc_r, doub
 }
 
 template <int C, bool ADI, bool DAMP, bool PER>
-__global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const double *va_pre, const double *vr_pre, ThetaSet in,
-                                                              int tiles, int rows, int advance_clock, const int *only_if)
+__device__ __forceinline__ void transport_theta_march_block(const Dev &P, const double *va_pre, const double *vr_pre, const ThetaSet &in,
+                                                            int tiles, int rows, int advance_clock, int vb, int nvb)
 {
     constexpr int periodic = PER ? 1 : 0;
-    if (only_if && !*only_if) // fallback behind k_transport_fused: runs only when that kernel gave up
-        return;
     // va_pre / vr_pre: the pre-transport (post-source, post-boundary) velocities; the new state goes to P's grids
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(vb, nvb) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chunk = wave / tiles;
     const int r0 = chunk * rows;
     const int nr = P.nr;
@@ -2279,6 +2287,17 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
     }
 #undef SH_PREV
 #undef SH_NEXT
+}
+
+// grid-stride wrapper, as k_transport_radial
+template <int C, bool ADI, bool DAMP, bool PER>
+__global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const double *va_pre, const double *vr_pre, ThetaSet in,
+                                                              int tiles, int rows, int advance_clock, const int *only_if, int nvb)
+{
+    if (only_if && !*only_if)
+        return;
+    for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x)
+        transport_theta_march_block<C, ADI, DAMP, PER>(P, va_pre, vr_pre, in, tiles, rows, advance_clock, vb, nvb);
 }
 
 // ===========================================================================
@@ -3141,14 +3160,17 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
             r.redge, r.tau, is_density);
 }
 
+#define FALLBACK_BLOCKS 256 /* grid of the idle in-stream fallback kernels */
 // one radial sweep + ring means (T1-T4); only_if: see k_transport_radial
 static void launch_radial(const Dev &P, const int *only_if, hipStream_t st)
 {
     const Launch2D l = launch2d((P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS, P.nphi);
+    const int gx = (int)l.grid.x, gy = (int)l.grid.y;
+    const dim3 grid(only_if && gx * gy > FALLBACK_BLOCKS ? FALLBACK_BLOCKS : gx * gy);
     if (l.block.x >= 64)
-        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<true>, l.grid, l.block, P, only_if);
+        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<true>, grid, l.block, P, only_if, gx, gy);
     else
-        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, l.grid, l.block, P, only_if);
+        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, grid, l.block, P, only_if, gx, gy);
 }
 static void launch_shift_means(const Dev &P, hipStream_t st)
 {
@@ -3157,7 +3179,7 @@ static void launch_shift_means(const Dev &P, hipStream_t st)
 }
 #define MARCHK(CC, PP, AA, DD)                                                                                      \
     KLAUNCH(KID_THETA_MARCH, (k_transport_theta_march<CC, AA, DD, PP>), grid, block, Wm, (const double *)P.vazi,   \
-            (const double *)P.vrad, inB, tiles, rows, advance, only_if)
+            (const double *)P.vrad, inB, tiles, rows, advance, only_if, nvb)
 #define MARCHC(CC, PP)                   \
     if (P.adiabatic) {                   \
         if (Wm.damp_in_step)             \
@@ -3182,7 +3204,8 @@ static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, 
         rows = atoi(e) > 0 ? atoi(e) : rows;
     const int chunks = (P.nr + rows - 1) / rows;
     const int waves = chunks * tiles;
-    const dim3 grid((waves + 3) / 4), block(256);
+    const int nvb = (waves + 3) / 4;
+    const dim3 grid(only_if && nvb > FALLBACK_BLOCKS ? FALLBACK_BLOCKS : nvb), block(256);
     if (!periodic) { // tiled: 2 cells per lane (1, 4 and 6 were measured slower), DPP lane shifts
         MARCHC(2, false)
     } else if (C == 1) {
