@@ -226,6 +226,13 @@ class Context:
     def init_physics(self):
         self._call("init_physics")
 
+    def disk_on_body_accel(self, x, y, r_object, smoothing_fixed=-1.0, cubic_smoothing_radius=0.0):
+        """ComputeDiskOnPlanetAccel without the all-reduce: [inner a_x, inner a_y, outer a_x, outer a_y]."""
+        out = (C.c_double * 4)()
+        self._call("disk_on_body_accel", _f64(x), _f64(y), _f64(r_object), _f64(smoothing_fixed),
+                   _f64(cubic_smoothing_radius), out)
+        return np.array(out[:], dtype=np.float64)
+
     def cfl(self) -> float:
         v = _f64()
         self._call("cfl", C.byref(v))

@@ -47,6 +47,7 @@ struct fcpt_ctx {
     double mx[FCPT_MAX_BODIES], my[FCPT_MAX_BODIES], mm[FCPT_MAX_BODIES], mrsm[FCPT_MAX_BODIES];
 };
 
+#define DOB_ROWS_HOST 8 /* = DOB_ROWS of k_disk_on_body */
 namespace {
 
 // routes this thread's launches to the context's profiler while it is recording
@@ -894,6 +895,22 @@ int fcpt_set_bodies_midstep(fcpt_ctx *c, int32_t n, const double *x, const doubl
 }
 
 // init_euler (SourceEuler.cpp:251-285) + the tail of init_physics (init.cpp:337-341)
+int fcpt_disk_on_body_accel(fcpt_ctx *c, double x, double y, double r_object, double smoothing_fixed,
+                            double cubic_smoothing_radius, double out[4])
+{
+    if (!c || !out)
+        return FCPT_EINVAL;
+    ProfScope prof_scope(c);
+    if (smoothing_fixed < 0.0 && c->P.adiabatic && !c->P.lazy_derived)
+        ensure_pressure(c); // the scale-height grid
+    double *d_out = c->P.cfl_part + 4 * (size_t)(((c->P.nphi + 255) / 256) * (c->P.nr / DOB_ROWS_HOST + 2));
+    launch_disk_on_body(c->P, x, y, r_object, smoothing_fixed, cubic_smoothing_radius, d_out, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FCPT_OK;
+}
+
 int fcpt_init_physics(fcpt_ctx *c)
 {
     if (!c)

@@ -1231,6 +1231,86 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
 }
 
 // ---------------------------------------------------------------------------
+// ComputeDiskOnPlanetAccel (Force.cpp:23-122): specific force of the slab's gas on an object.
+// A thread owns a phi column over DOB_ROWS active rings; block sums in a fixed order into
+// part[block][4] = {inner a_x, inner a_y, outer a_x, outer a_y}, folded by k_disk_on_body_final
+// (two fixed-order stages: the result is deterministic, unlike an atomic accumulation).
+#define DOB_ROWS 8
+__global__ void __launch_bounds__(256) k_disk_on_body(const Dev P, double x, double y, double r_object,
+                                                     double smoothing_fixed, double r_sm, double *part)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r0 = P.first_active + blockIdx.y * DOB_ROWS;
+    const int r1 = r0 + DOB_ROWS < P.active_size ? r0 + DOB_ROWS : P.active_size;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (j < P.nphi) {
+        const double cj = P.cosphi[j], sj = P.sinphi[j];
+        for (int i = r0; i < r1; ++i) {
+            const double rm = P.Rmed[i];
+            double smooth = smoothing_fixed;
+            if (smoothing_fixed < 0.0) { // compute_smoothing_scaleheight (Force.cpp:124-131)
+                double H;
+                if (!P.adiabatic) {
+                    H = P.cs_ring[i] * P.g_inv_omk[i];
+                } else if (P.lazy_derived) {
+                    const double cs = sqrt(P.gamma * (P.gamma - 1.0) * P.energy[IDX(i, j)] / P.sigma[IDX(i, j)]);
+                    H = cs / (sqrt(P.gamma)) * P.g_inv_omk[i];
+                } else {
+                    H = P.scale_height[IDX(i, j)];
+                }
+                smooth = P.thickness_smoothing * H;
+            }
+            const double cellmass = P.Surf[i] * P.sigma[IDX(i, j)];
+            const double dx = rm * cj - x;
+            const double dy = rm * sj - y;
+            const double dist_sm_2 = dx * dx + dy * dy + smooth * smooth;
+            const double dist_sm = sqrt(dist_sm_2);
+            const double inv_dist_sm_3 = 1.0 / (dist_sm_2 * dist_sm);
+            double klahr = 1.0;
+            if (r_sm > 0.0 && dist_sm < r_sm) {
+                const double q = dist_sm / r_sm;
+                klahr = -(3.0 * ((q * q) * (q * q)) - 4.0 * (q * q * q));
+            }
+            const double fx = P.G * cellmass * dx * inv_dist_sm_3 * klahr;
+            const double fy = P.G * cellmass * dy * inv_dist_sm_3 * klahr;
+            const int o = rm < r_object ? 0 : 2;
+            a[o] += fx;
+            a[o + 1] += fy;
+        }
+    }
+    __shared__ double s_a[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = a[q];
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0)
+            s_a[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        part[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] =
+            (s_a[0][threadIdx.x] + s_a[1][threadIdx.x]) + (s_a[2][threadIdx.x] + s_a[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) k_disk_on_body_final(const double *part, int nblocks, double *out)
+{
+    __shared__ double s_a[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = 0.0;
+        for (int n = threadIdx.x; n < nblocks; n += blockDim.x)
+            v += part[n * 4 + q];
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0)
+            s_a[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        out[threadIdx.x] = (s_a[0][threadIdx.x] + s_a[1][threadIdx.x]) + (s_a[2][threadIdx.x] + s_a[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
 // boundary_conditions/{zero_gradient,reference,reflecting,outflow,keplerian_*,zero_shear}.cpp
 // called in the order of boundary_conditions.cpp:65-114; one thread per phi column.
 // All loads first, then all stores: the ghost values only depend on active rings (or on the
@@ -3360,6 +3440,15 @@ void launch_derived(const Dev &P, hipStream_t st)
 
 void launch_pressure(const Dev &P, hipStream_t st) { LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P); }
 void launch_temperature(const Dev &P, hipStream_t st) { LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P); }
+
+void launch_disk_on_body(const Dev &P, double x, double y, double r_object, double smoothing_fixed, double r_sm, double *out,
+                         hipStream_t st)
+{
+    const int nrows = P.active_size - P.first_active;
+    const dim3 grid((P.nphi + 255) / 256, nrows > 0 ? (nrows + DOB_ROWS - 1) / DOB_ROWS : 1), block(256);
+    KLAUNCH(KID_POTENTIAL, k_disk_on_body, grid, block, P, x, y, r_object, smoothing_fixed, r_sm, P.cfl_part);
+    KLAUNCH(KID_POTENTIAL, k_disk_on_body_final, dim3(1), dim3(256), (const double *)P.cfl_part, (int)(grid.x * grid.y), out);
+}
 
 void launch_cfl(const Dev &P, int apply_policy, int use_part, hipStream_t st)
 {

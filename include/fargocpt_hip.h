@@ -278,6 +278,19 @@ int fcpt_set_bodies(fcpt_ctx *ctx, int32_t n, const double *x, const double *y, 
 int fcpt_set_bodies_midstep(fcpt_ctx *ctx, int32_t n, const double *x, const double *y, const double *mass,
                             const double *cubic_smoothing_radius);
 
+/* Specific force of this slab's gas on an object at (x, y): ComputeDiskOnPlanetAccel
+ * (src/Force.cpp:23-122) without its MPI_Allreduce -- out = {a_x, a_y} summed over the cells
+ * of the rings inside `r_object` (the object's distance to the origin) followed by {a_x, a_y}
+ * of the rings outside, over this slab's active rings; the caller adds the slabs' four sums
+ * (the reference's 4-double all-reduce) and then inner + outer.  Smoothing as
+ * compute_smoothing (src/Force.cpp:124-159): `smoothing_fixed` < 0 selects
+ * ThicknessSmoothing x H of each cell, a value >= 0 is used as it is (planet-location smoothing,
+ * or 0 for the star with compatibility_no_star_smoothing).  `cubic_smoothing_radius` > 0 applies
+ * the derivative of the Klahr & Kley cubic smoothing inside that distance.
+ * Blocks until the four sums are on the host. */
+int fcpt_disk_on_body_accel(fcpt_ctx *ctx, double x, double y, double r_object, double smoothing_fixed,
+                            double cubic_smoothing_radius, double out[4]);
+
 /* After the initial Sigma/v/energy upload: init_euler (src/SourceEuler.cpp:251-285:
  * sound speed, pressure, temperature, scale height, viscosity), the first
  * potential, copy_initial_values + apply_boundary_condition + copy_initial_values

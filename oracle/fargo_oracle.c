@@ -757,6 +757,51 @@ int orc_set_bodies(orc_ctx *c, int32_t n, const double *x, const double *y, cons
     return FCPT_OK;
 }
 
+/* Force.cpp:23-122 ComputeDiskOnPlanetAccel (local sums, no Allreduce; correct_disk_selfgravity
+ * off); smoothing: Force.cpp:124-159 compute_smoothing */
+int orc_disk_on_body_accel(orc_ctx *c, double x, double y, double r_object, double smoothing_fixed,
+                           double cubic_smoothing_radius, double out[4])
+{
+    if (!c || !out)
+        return FCPT_EINVAL;
+    const int Nphi = c->nphi;
+    double axi = 0.0, ayi = 0.0, axo = 0.0, ayo = 0.0;
+    for (int nr = c->s.radial_first_active; nr < c->s.radial_active_size; ++nr) {
+        for (int naz = 0; naz < Nphi; ++naz) {
+            const double smooth = smoothing_fixed >= 0.0
+                                      ? smoothing_fixed
+                                      : c->d.thickness_smoothing * c->scale_height[IDX(c, nr, naz)];
+            const double xc = c->Rmed[nr] * cos(c->dphi * (double)naz); /* SideEuler.cpp:60-63 */
+            const double yc = c->Rmed[nr] * sin(c->dphi * (double)naz);
+            const double cellmass = c->Surf[nr] * c->sigma[IDX(c, nr, naz)];
+            const double dx = xc - x;
+            const double dy = yc - y;
+            const double dist_2 = dx * dx + dy * dy;
+            const double dist_sm_2 = dist_2 + smooth * smooth;
+            const double dist_sm = sqrt(dist_sm_2);
+            const double dist_sm_3 = dist_sm_2 * dist_sm;
+            const double inv_dist_sm_3 = 1.0 / dist_sm_3;
+            double smooth_factor_klahr = 1.0;
+            if (cubic_smoothing_radius > 0.0 && dist_sm < cubic_smoothing_radius) {
+                const double q = dist_sm / cubic_smoothing_radius;
+                smooth_factor_klahr = -(3.0 * ((q * q) * (q * q)) - 4.0 * (q * q * q));
+            }
+            if (c->Rmed[nr] < r_object) {
+                axi += c->d.G * cellmass * dx * inv_dist_sm_3 * smooth_factor_klahr;
+                ayi += c->d.G * cellmass * dy * inv_dist_sm_3 * smooth_factor_klahr;
+            } else {
+                axo += c->d.G * cellmass * dx * inv_dist_sm_3 * smooth_factor_klahr;
+                ayo += c->d.G * cellmass * dy * inv_dist_sm_3 * smooth_factor_klahr;
+            }
+        }
+    }
+    out[0] = axi;
+    out[1] = ayi;
+    out[2] = axo;
+    out[3] = ayo;
+    return FCPT_OK;
+}
+
 /* ------------------------------------------------------------------------ */
 /* EOS helpers                                                               */
 

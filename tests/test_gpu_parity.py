@@ -250,3 +250,32 @@ def test_transport_beyond_shear_limit_falls_back(product, oracle, monkeypatch):
     monkeypatch.setenv("FCPT_TRANSPORT_FALLBACK", "0")
     (a, _), (b, _) = run_pair(product, oracle, d, 3, bodies=bodies, dt_scale=4.0)
     assert rel_err(a["vrad"], b["vrad"]) > 1e-6 or not np.isfinite(a["vrad"]).all()
+
+
+@pytest.mark.parametrize("adiabatic", [False, True])
+def test_disk_on_body_accel(product, oracle, adiabatic):
+    """ComputeDiskOnPlanetAccel (Force.cpp:23-122): the four sums (inner /
+    outer rings, x / y) of the gas's specific force on the planet, after a few steps have built the
+    wake.  The sums cancel to ~1e-3 of their terms in a nearly axisymmetric disk, so the bar is set
+    against the sum of the terms' magnitudes (G M_disk / d^2 scale), not against the net value."""
+    from fargocpt_amd import driver
+    d = setups.planet_disk(product, 48, 256, adiabatic=adiabatic)
+    bodies = setups.jupiter_bodies(d)
+    res = []
+    for L in (product, oracle):
+        ctx = driver.make_context(L, d, bodies=bodies)
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        S.run(8)
+        hill = (bodies[2][1] / 3.0) ** (1.0 / 3.0)
+        a = [ctx.disk_on_body_accel(1.0, 0.0, 1.0),                           # H-based smoothing per cell
+             ctx.disk_on_body_accel(1.0, 0.0, 1.0, 0.6 * 0.05, 0.5 * hill),   # planet-location + cubic smoothing
+             ctx.disk_on_body_accel(0.0, 0.0, 0.0, 0.0, 0.0)]                 # the star, no smoothing
+        sig = ctx.download(B.F_SIGMA)
+        res.append((a, sig))
+        ctx.close()
+    (a, sig), (b, _) = res
+    scale = float(np.abs(sig).sum()) * 2 * np.pi * 2.5 ** 2 / sig.size  # ~ G M_disk with G = 1, d ~ 1
+    for x, y in zip(a, b):
+        assert np.all(np.abs(x - y) <= 1e-10 * np.abs(y).max() + 1e-12 * scale), (x, y)
+        assert np.abs(y).max() > 0

@@ -80,3 +80,21 @@ def test_one_vs_many_slabs_oracle(product, oracle):
     assert dta == dtb
     for k in a:
         assert rel_err(a[k], b[k]) == 0.0
+
+
+def test_disk_on_body_accel_symmetries(product, oracle):
+    """ComputeDiskOnPlanetAccel restated (Force.cpp:23-122): for an axisymmetric disk the force on an
+    object on the x axis has no y component, the rings inside pull inward and the rings outside pull
+    outward; the force on the star vanishes."""
+    from fargocpt_amd import driver, setups
+    d = setups.planet_disk(product, 40, 96)
+    ctx = driver.make_context(oracle, d, bodies=setups.jupiter_bodies(d))
+    axi, ayi, axo, ayo = ctx.disk_on_body_accel(1.0, 0.0, 1.0)
+    assert axi < 0.0 < axo
+    assert abs(ayi) < 1e-12 * abs(axi) and abs(ayo) < 1e-12 * abs(axo)
+    star = ctx.disk_on_body_accel(0.0, 0.0, 0.0, 0.0, 0.0)
+    assert np.all(np.abs(star) < 1e-12 * abs(axo))
+    # planet-location smoothing weakens the pull of the nearby rings
+    sm = ctx.disk_on_body_accel(1.0, 0.0, 1.0, 0.3)
+    assert abs(sm[0]) < abs(axi) and abs(sm[2]) < abs(axo)
+    ctx.close()
