@@ -20,6 +20,8 @@ MAX_BODIES = 8
 SPACING_ARITHMETIC, SPACING_LOGARITHMIC, SPACING_EXPONENTIAL = 0, 1, 2
 EOS_ISOTHERMAL, EOS_IDEAL = 0, 1
 ARTVISC_NONE, ARTVISC_TW, ARTVISC_SN = 0, 1, 2
+OPACITY_LIN, OPACITY_BELL, OPACITY_CONST, OPACITY_SIMPLE = 0, 1, 2, 3
+BETAREF_ZERO, BETAREF_REFERENCE, BETAREF_MODEL, BETAREF_FLOOR = 0, 1, 2, 3
 LIMITER_VANLEER, LIMITER_MC = 0, 1
 INTEGRATOR_EULER, INTEGRATOR_LEAPFROG = 0, 1
 (BC_ZEROGRADIENT, BC_REFERENCE, BC_REFLECTING, BC_OUTFLOW, BC_KEPLERIAN, BC_ZEROSHEAR,
@@ -68,6 +70,12 @@ class Desc(C.Structure):
         ("G", _f64), ("Rgas", _f64), ("sigma_sb", _f64), ("c_light", _f64),
         ("ic", _i32), ("set_sigma0", _i32), ("disk_mass", _f64),
         ("initialize_vradial_zero", _i32), ("initialize_pure_keplerian", _i32),
+        ("cooling_surface", _i32), ("opacity", _i32),
+        ("cooling_radiative_factor", _f64), ("kappa_const", _f64), ("kappa_factor", _f64),
+        ("tau_factor", _f64), ("tau_min", _f64), ("density_factor", _f64),
+        ("cooling_beta", _i32), ("cooling_beta_reference", _i32),
+        ("cooling_beta_value", _f64), ("cooling_beta_ramp_up", _f64),
+        ("temperature_cgs", _f64), ("density_cgs", _f64), ("opacity_cgs", _f64),
     ]
 
     def copy(self) -> "Desc":

@@ -231,6 +231,22 @@ bool enqueue_kick(fcpt_ctx *c)
 void enqueue_potential(fcpt_ctx *c, bool midstep)
 {
     Dev &P = c->P;
+    if (midstep && P.adiabatic && P.lazy_derived) {
+        // the mid-step potential of step_LeapFrog sees the scale height of the first kick (left in the
+        // grid by k_source_march_adi), not one derived from the transported state
+        Dev M = P;
+        M.lazy_derived = 0;
+        if (c->has_mid)
+            for (int k = 0; k < P.nbodies; ++k) {
+                M.bx[k] = c->mx[k];
+                M.by[k] = c->my[k];
+                M.bm[k] = c->mm[k];
+                M.brsm[k] = c->mrsm[k];
+            }
+        launch_potential(M, c->stream);
+        c->potential_valid = false;
+        return;
+    }
     if (midstep && c->has_mid) {
         Dev M = P;
         for (int k = 0; k < P.nbodies; ++k) {
@@ -299,7 +315,10 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt)
         c->pressure_valid = false; // compute_pressure(data), simulation.cpp:378
         if (P.adiabatic && !P.lazy_derived)
             ensure_pressure(c);
-        if (enqueue_kick(c)) { // result in the *_b buffers: bring it home
+        c->P.kick_time_shift = 1; // SubStep3 of the second kick runs at midstep_time (simulation.cpp:388)
+        const bool home = enqueue_kick(c);
+        c->P.kick_time_shift = 0;
+        if (home) { // result in the *_b buffers: bring it home
             const size_t ns = (size_t)P.nr * P.nphi * sizeof(double), nv = (size_t)(P.nr + 1) * P.nphi * sizeof(double);
             (void)hipMemcpyAsync(P.vrad, P.vrad_b, nv, hipMemcpyDeviceToDevice, st);
             (void)hipMemcpyAsync(P.vazi, P.vazi_b, ns, hipMemcpyDeviceToDevice, st);
@@ -346,6 +365,15 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     }
     if (!d->body_force_from_potential) {
         set_error("BodyForceFromPotential: no is not supported");
+        return FCPT_EINVAL;
+    }
+    if ((d->cooling_surface || d->cooling_beta) && d->eos != FCPT_EOS_IDEAL) {
+        set_error("cooling needs EquationOfState: ideal");
+        return FCPT_EINVAL;
+    }
+    if (d->cooling_surface && d->opacity != FCPT_OPACITY_LIN && d->opacity != FCPT_OPACITY_CONST &&
+        d->opacity != FCPT_OPACITY_SIMPLE) {
+        set_error("Opacity: only Lin, Const and Simple are supported");
         return FCPT_EINVAL;
     }
     if ((long long)(d->nr_global + 1) * (long long)d->nphi >= (1ll << 31)) {
@@ -435,6 +463,12 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
             t5[i] = 1.0 / std::sqrt(d->G * d->hydro_center_mass / (rm * rm * rm));
         }
         if (!rc) rc = dev_upload(c, &P.g_inv_omk.p, t5);
+        std::vector<double> t6(nr + 1, 0.0);
+        for (int i = 0; i < nr; ++i) {
+            const double rm = g.Rmed[i];
+            t6[i] = std::sqrt(d->G * d->hydro_center_mass / (rm * rm * rm));
+        }
+        if (!rc) rc = dev_upload(c, &P.g_omk.p, t6);
         std::vector<RadRow> rt(nr + 2);
         for (int k = -1; k <= nr; ++k) {
             const bool open = k > 0 && k < nr;
@@ -622,6 +656,21 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     P.aspect_ratio = d->aspect_ratio;
     P.flaring_index = d->flaring_index;
     P.tmin = d->minimum_temperature;
+    P.cooling_surface = d->cooling_surface;
+    P.opacity = d->opacity;
+    P.cooling_beta = d->cooling_beta;
+    P.cooling_beta_reference = d->cooling_beta_reference;
+    P.cooling_radiative_factor = d->cooling_radiative_factor;
+    P.kappa_const = d->kappa_const;
+    P.kappa_factor = d->kappa_factor;
+    P.tau_factor = d->tau_factor;
+    P.tau_min = d->tau_min;
+    P.density_factor = d->density_factor;
+    P.cooling_beta_value = d->cooling_beta_value;
+    P.cooling_beta_ramp_up = d->cooling_beta_ramp_up;
+    P.temperature_cgs = d->temperature_cgs;
+    P.density_cgs = d->density_cgs;
+    P.opacity_cgs = d->opacity_cgs;
     P.emin_fac = d->minimum_temperature / d->mu * d->Rgas / (d->adiabatic_index - 1.0);
     P.emax_fac = d->maximum_temperature / d->mu * d->Rgas / (d->adiabatic_index - 1.0);
     P.b_fac = d->mu * (d->adiabatic_index - 1.0) / d->Rgas;
@@ -934,6 +983,12 @@ int fcpt_init_physics(fcpt_ctx *c)
     const size_t ns = (size_t)P.nr * P.nphi * sizeof(double);
     HIPCHK(hipMemsetAsync(P.qplus, 0, ns, st));
     HIPCHK(hipMemsetAsync(P.qminus, 0, ns, st));
+    if (P.adiabatic && (P.cooling_surface || P.cooling_beta)) {
+        // ... but Q- does not vanish: calculate_qminus + the 1/alpha of compute_heating_cooling_for_CFL
+        Dev I = P;
+        I.cooling_at_init = 1;
+        launch_substep3_cooling_only(I, st);
+    }
     if (int rc = copy_initial_values(c))
         return rc;
     apply_boundary(c, false);

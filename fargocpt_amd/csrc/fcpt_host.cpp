@@ -369,6 +369,22 @@ int fcpt_desc_default(fcpt_desc *d)
     d->disk_mass = 0.01;
     d->initialize_vradial_zero = 0;
     d->initialize_pure_keplerian = 0;
+    // cooling (src/parameters.cpp:399-490,661-665)
+    d->cooling_surface = 0;
+    d->opacity = FCPT_OPACITY_LIN;
+    d->cooling_radiative_factor = 1.0;
+    d->kappa_const = 1.0;
+    d->kappa_factor = 1.0;
+    d->tau_factor = 0.5;
+    d->tau_min = 0.01;
+    d->density_factor = std::sqrt(2.0 * M_PI);
+    d->cooling_beta = 0;
+    d->cooling_beta_reference = FCPT_BETAREF_ZERO;
+    d->cooling_beta_value = 1.0;
+    d->cooling_beta_ramp_up = 0.0;
+    d->temperature_cgs = Temp0;
+    d->density_cgs = M0 / (L0 * L0 * L0);
+    d->opacity_cgs = L0 * L0 / M0;
     return FCPT_OK;
 }
 

@@ -177,6 +177,12 @@ struct Dev {
     int alpha_viscosity;
     double gamma, mu, Rgas, G, Mc, sigma_sb, c_light, aspect_ratio, flaring_index;
     double tmin, tmax, sigma_floor_abs, sigma_floor_rel, sigma0_val;
+    // cooling terms of SubStep3 (calculate_qminus)
+    int cooling_surface, opacity, cooling_beta, cooling_beta_reference, cooling_at_init;
+    int kick_time_shift; // 1: second leapfrog kick -- its SubStep3 runs at clk.time - clk.dt (midstep_time)
+    double cooling_radiative_factor, kappa_const, kappa_factor, tau_factor, tau_min, density_factor;
+    double cooling_beta_value, cooling_beta_ramp_up, temperature_cgs, density_cgs, opacity_cgs;
+    CArr g_omk; // Omega_K(Rmed[i])
     double emin_fac, emax_fac; // T_min|max / mu * R / (gamma - 1): energy floor / ceiling per unit Sigma
     double b_fac;              // mu (gamma - 1) / R of SubStep3's alpha
     double alpha, nu_const, radial_viscosity_factor, art_visc_factor, heating_viscous_factor;

@@ -53,6 +53,7 @@ struct TransportResult {
     double *sigma, *energy, *vrad, *vazi;
 };
 TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st);
+void launch_substep3_cooling_only(const Dev &P, hipStream_t st);
 void launch_disk_on_body(const Dev &P, double x, double y, double r_object, double smoothing_fixed, double r_sm, double *out,
                          hipStream_t st);
 void launch_source_fused(const Dev &P, hipStream_t st);

@@ -480,6 +480,108 @@ __device__ __forceinline__ double substep3_alpha(const Dev &P, double H, double 
     const double b2 = b * b;
     return 1.0 + 2.0 * H * 4.0 * P.sigma_sb / P.c_light * (b2 * b2) * (energy * energy * energy);
 }
+// opacity.cpp:45-168 lin(): Lin & Papaloizou (1985), cgs in / cgs out
+__device__ double opacity_lin(double density, double temperature)
+{
+    const double power1 = 4.44444444e-2, power2 = 2.381e-2, power3 = 2.267e-1;
+    const double t234 = 1.6e3, t456 = 5.7e3, t678 = 2.28e6;
+    const double ak1 = 2.e-4, ak2 = 2.e16, ak3 = 5.e-3;
+    const double bk3 = 50., bk4 = 2.e-2, bk5 = 2.e4, bk6 = 1.e4, bk7 = 1.5e10, bk8 = 0.348;
+    if (temperature > t234 * pow(density, power1)) {
+        const double ts4 = 1.e-4 * temperature;
+        const double density13 = pow(density, 1.0 / 3.0);
+        const double density23 = density13 * density13;
+        const double ts42 = ts4 * ts4;
+        const double ts44 = ts42 * ts42;
+        const double ts48 = ts44 * ts44;
+        if (temperature > t456 * pow(density, power2)) {
+            if ((temperature < t678 * pow(density, power3)) || (density <= 1e-10)) {
+                const double o5 = bk5 * density23 * ts42 * ts4;
+                const double o6 = bk6 * density13 * ts48 * ts42;
+                const double o7 = bk7 * density / (ts42 * sqrt(ts4));
+                const double o6an = o6 * o6, o7an = o7 * o7;
+                return pow(pow(o6an * o7an / (o6an + o7an), 2.0) +
+                               pow(o5 / (1.0 + pow(ts4 / (1.1 * pow(density, 0.04762)), 10.0)), 4.0),
+                           0.25);
+            } else {
+                const double o7 = bk7 * density / (ts42 * sqrt(ts4));
+                const double o8 = bk8;
+                const double o7an = o7 * o7, o8an = o8 * o8;
+                return pow(o7an * o7an + o8an * o8an, 0.25);
+            }
+        } else {
+            const double o3 = bk3 * ts4;
+            const double o4 = bk4 * density23 / (ts48 * ts4);
+            const double o5 = bk5 * density23 * ts42 * ts4;
+            const double o4an = pow(o4, 4.0), o3an = pow(o3, 4.0);
+            return pow((o4an * o3an / (o4an + o3an)) + pow(o5 / (1.0 + 6.561e-5 / ts48), 4.0), 0.25);
+        }
+    } else {
+        const double t2 = temperature * temperature;
+        const double t4 = t2 * t2;
+        const double t8 = t4 * t4;
+        const double t10 = t8 * t2;
+        const double o1 = ak1 * t2;
+        const double o2 = ak2 * temperature / t8;
+        const double o3 = ak3 * temperature;
+        const double o1an = o1 * o1, o2an = o2 * o2;
+        return pow(pow(o1an * o2an / (o1an + o2an), 2.0) + pow(o3 / (1 + 1.e22 / t10), 4.0), 0.25);
+    }
+}
+// midplane_density + kappa_eff at one cell (compute.cpp:17-87): the effective optical depth
+__device__ __forceinline__ double tau_eff_of(const Dev &P, double sigma, double H, double temperature)
+{
+    const double rho = sigma / (P.density_factor * H);
+    const double temperatureCGS = temperature * P.temperature_cgs;
+    double kappa;
+    if (P.opacity == FCPT_OPACITY_LIN)
+        kappa = opacity_lin(rho * P.density_cgs, temperatureCGS) * (1.0 / P.opacity_cgs);
+    else if (P.opacity == FCPT_OPACITY_CONST)
+        kappa = P.kappa_const;
+    else
+        kappa = P.kappa_const * (temperatureCGS * temperatureCGS);
+    kappa = P.kappa_factor * kappa;
+    const double tau = P.tau_factor * (1.0 / P.density_factor) * kappa * sigma;
+    if (P.opacity == FCPT_OPACITY_SIMPLE)
+        return 3.0 / 8.0 * tau; // D'Angelo et al. 2003 eq. (28)
+    return 3.0 / 8.0 * tau + sqrt(3.0) / 4.0 + 1.0 / (4.0 * tau + P.tau_min);
+}
+// calculate_qminus (SourceEuler.cpp:931-950) at one cell of rows [1, Nr-1): beta cooling
+// (thermal_relaxation :632-786, without the opacity-based Ziampras variants) and thermal surface
+// cooling (:790-820).  tau_eff is returned for SubStep3's low-density branch (0 without surface cooling).
+struct Cooling {
+    double qminus, tau_eff;
+};
+__device__ __forceinline__ Cooling cooling_terms(const Dev &P, int i, int cell, double sigma, double energy, double H)
+{
+    Cooling c = {0.0, 0.0};
+    if (P.cooling_beta && !(P.cooling_at_init && P.cooling_beta_reference == FCPT_BETAREF_REFERENCE)) {
+        double beta_inv = 1 / P.cooling_beta_value;
+        if (P.cooling_beta_ramp_up > 0.0) {
+            const double t = P.clk->time - (P.kick_time_shift ? P.clk->dt : 0.0);
+            const double x = 2 * t / P.cooling_beta_ramp_up;
+            beta_inv = beta_inv * (1 - exp(-(x * x)));
+        }
+        double delta_E = energy;
+        if (P.cooling_beta_reference == FCPT_BETAREF_REFERENCE) {
+            delta_E -= P.energy0[cell] / P.sigma0[cell] * sigma;
+        } else if (P.cooling_beta_reference == FCPT_BETAREF_MODEL) {
+            const double E0 = 1.0 / (P.gamma - 1.0) * (P.aspect_ratio * P.aspect_ratio) *
+                              pow(P.Rmed[i], 2.0 * P.flaring_index - 1.0) * P.G * P.Mc * sigma;
+            delta_E -= E0;
+        } else if (P.cooling_beta_reference == FCPT_BETAREF_FLOOR) {
+            delta_E -= P.tmin * sigma / P.mu * P.Rgas / (P.gamma - 1.0);
+        }
+        c.qminus += delta_E * P.g_omk[i] * beta_inv;
+    }
+    if (P.cooling_surface) {
+        const double T = P.mu / P.Rgas * (P.gamma - 1.0) * energy / sigma; // compute_temperature
+        c.tau_eff = tau_eff_of(P, sigma, H, T);
+        const double T2 = T * T, Tm2 = P.tmin * P.tmin;
+        c.qminus += P.cooling_radiative_factor * 2 * P.sigma_sb * (T2 * T2 - Tm2 * Tm2) / c.tau_eff;
+    }
+    return c;
+}
 // SourceEuler.cpp:1000-1048: energy update of SubStep3 (update_energy != 0) or only the
 // alpha rescaling of compute_heating_cooling_for_CFL (:1520-1545)
 template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
@@ -490,14 +592,16 @@ template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
     const double sigma = P.sigma[IDX(i, j)];
     const double energy = P.energy[IDX(i, j)];
     const double alpha = substep3_alpha(P, H, sigma, energy);
+    const Cooling cool = cooling_terms(P, i, IDX(i, j), sigma, energy, H);
     const double Qplus = P.qplus[IDX(i, j)] / alpha;
-    double Qminus = P.qminus[IDX(i, j)] / alpha;
+    double Qminus = (P.qminus[IDX(i, j)] + cool.qminus) / alpha;
     if (update_energy) {
         double energy_new = energy + dt * (Qplus - Qminus);
         const double SigmaFloor = 10.0 * P.sigma0_val * P.sigma_floor_rel;
         if (sigma < SigmaFloor) {
-            // tau_eff is 0 without cooling => equilibrium energy 0 (raised to the floor below)
-            energy_new = 0.0;
+            // the energy at which the current heating and cooling balance (0 without surface cooling: tau_eff = 0)
+            const double e4 = Qplus * cool.tau_eff / (2.0 * P.sigma_sb);
+            energy_new = sqrt(sqrt(e4)) * (P.Rgas / P.mu * sigma / (P.gamma - 1.0));
             Qminus = Qplus;
         }
         P.energy[IDX(i, j)] = energy_new;
@@ -997,6 +1101,7 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     const double gm1 = P.gamma - 1.0;
     const double inv_sqrt_gamma = 1.0 / sqrt(P.gamma);
     const bool dissipate = P.art_visc_dissipation != 0;
+    const bool cooling = P.cooling_surface != 0 || P.cooling_beta != 0;
 
 #define NEXT(x) lane_next(x) /* value of cell j+1 */
 #define PREV(x) lane_prev(x) /* value of cell j-1 */
@@ -1203,11 +1308,19 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
                     if (row_va) { // SubStep3, rows [1, Nr-1)
                         const double bb = P.b_fac * fast_rcp(S_2), b2 = bb * bb; // substep3_alpha
                         const double alpha = 1.0 + 2.0 * H_2 * 4.0 * P.sigma_sb / P.c_light * (b2 * b2) * (e * e * e);
-                        qplus = qplus * fast_rcp(alpha);
+                        const double ralpha = fast_rcp(alpha);
+                        double tau_eff = 0.0;
+                        if (cooling) { // calculate_qminus
+                            const Cooling cool = cooling_terms(P, k, IDX(k, j), S_2, e, H_2);
+                            qminus = cool.qminus * ralpha;
+                            tau_eff = cool.tau_eff;
+                        }
+                        qplus = qplus * ralpha;
                         double energy_new = e + dt * (qplus - qminus);
                         const double SigmaFloor = 10.0 * P.sigma0_val * P.sigma_floor_rel;
                         if (S_2 < SigmaFloor) {
-                            energy_new = 0.0;
+                            const double e4 = qplus * tau_eff / (2.0 * P.sigma_sb);
+                            energy_new = sqrt(sqrt(e4)) * (P.Rgas / P.mu * S_2 / (P.gamma - 1.0));
                             qminus = qplus;
                         }
                         e = energy_new;
@@ -1221,6 +1334,11 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
                         P.energy_b[IDX(k, j)] = e;
                         P.qplus[IDX(k, j)] = qplus;
                         P.qminus[IDX(k, j)] = qminus;
+                        // step_LeapFrog evaluates the mid-step potential with the scale height this kick's
+                        // recalculate_viscosity left behind (simulation.cpp:340-378), not with that of the
+                        // transported state: keep the grid for it
+                        if (P.leapfrog)
+                            P.scale_height[IDX(k, j)] = H_2;
                     }
                 }
             }
@@ -3211,6 +3329,12 @@ void launch_viscous_update(const Dev &P, hipStream_t st)
 {
     LAUNCH2D(KID_VISC_VA, k_visc_va, P.nr - 2, P);
     LAUNCH2D(KID_VISC_VR, k_visc_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
+}
+
+void launch_substep3_cooling_only(const Dev &P, hipStream_t st)
+{
+    // compute_heating_cooling_for_CFL at init (SourceEuler.cpp:1507-1547): Q+ = 0 (gas at rest), Q- / alpha
+    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr - 2, P, 0);
 }
 
 void launch_substep3(const Dev &P, int update_energy, hipStream_t st)

@@ -10,6 +10,7 @@ from . import binding as B
 # code-unit conversion of the reference's default units (src/units.cpp:158-185)
 _G_CGS, _KB, _MU = 6.67430e-8, 1.380649e-16, 1.66053906660e-24
 _L0, _M0 = 1.495978707e13, 1.988409870698051e33
+_T0 = (_L0 ** 3 / (_G_CGS * _M0)) ** 0.5              # seconds per code time
 TEMP0_K = _G_CGS * _MU / _KB * _M0 / _L0            # Kelvin per code temperature
 SIGMA_CGS = _M0 / (_L0 * _L0)                        # g/cm^2 per code surface density
 M_JUP = 9.547919e-4                                  # jupiterMass / solMass
@@ -120,6 +121,57 @@ def planet_disk(lib: B.Library, nr=128, nphi=384, adiabatic=False, damping=True,
         arr[0] = arr[1] = B.DAMP_REFERENCE
     d.nsnapshots, d.nmonitor, d.monitor_timestep = 50, 10, 0.628
     return d
+
+
+def temperature_test(lib: B.Library, nr=100, nphi=2) -> B.Desc:
+    """test/TemperatureTest/angelo.yml: viscously heated, radiatively cooled disk in thermal
+    equilibrium (D'Angelo et al. 2003): ideal EOS, constant nu = 5e16 cm^2/s, kappa = 2e-6 T^2 cm^2/g
+    (Opacity: Simple), SurfaceCooling: thermal, HeatingViscous, leapfrog, no artificial viscosity,
+    100 x 2 cells on r in [1, 20] au."""
+    d = lib.desc_default()
+    d.nr_global, d.nphi = nr, nphi
+    d.rmin, d.rmax, d.radial_spacing = 1.0, 20.0, B.SPACING_LOGARITHMIC
+    d.ic = B.IC_PROFILE
+    d.sigma0 = 197.0 / SIGMA_CGS
+    d.sigma_slope, d.sigma_floor = 0.0, 1e-9
+    d.mu = 2.35
+    d.aspect_ratio = (352.0 / TEMP0_K * 1.0 / d.mu) ** 0.5   # Temperature0: 352 K (Interpret.cpp:194-197)
+    d.flaring_index = 0.5
+    d.viscous_alpha, d.constant_viscosity = 0.0, 5.0e16 / (_L0 * _L0 / _T0)
+    d.artificial_viscosity, d.artificial_viscosity_dissipation = B.ARTVISC_NONE, 0
+    d.artificial_viscosity_factor = 1.0
+    d.eos, d.adiabatic_index = B.EOS_IDEAL, 1.4
+    d.heating_viscous, d.heating_viscous_factor = 1, 1.0
+    d.cooling_surface, d.cooling_radiative_factor = 1, 1.0
+    d.opacity, d.kappa_const = B.OPACITY_SIMPLE, 17.770441374359926
+    d.tau_factor, d.density_factor = 1.0, 2.0
+    d.minimum_temperature, d.maximum_temperature = 3.0 / TEMP0_K, 1.0e7 / TEMP0_K
+    d.cfl, d.heating_cooling_cfl_limit = 0.5, 1000.0
+    d.thickness_smoothing = 0.0
+    d.fast_transport = 1
+    d.initialize_vradial_zero = 1
+    _composite(d, 0, "reflecting")
+    _composite(d, 1, "reflecting")
+    d.damping = 1
+    d.damping_inner_limit, d.damping_outer_limit = 1.10, 0.90
+    d.damping_time_factor, d.damping_time_radius_outer = 3.0e-1, d.rmax
+    for arr in (d.damp_vaz, d.damp_sigma, d.damp_energy):
+        arr[0] = arr[1] = B.DAMP_NONE
+    d.damp_vrad[0] = d.damp_vrad[1] = B.DAMP_ZERO
+    d.omega_frame = 0.0
+    d.integrator = B.INTEGRATOR_LEAPFROG
+    d.nsnapshots, d.nmonitor, d.monitor_timestep = 10, 10, 6.28e2
+    return d
+
+
+def temperature_test_theory(d: B.Desc, radii_med, sigma_code):
+    """Equilibrium temperature (code units) of test/TemperatureTest/check_results.py,
+    T = sqrt(27/128 kappa0 nu / sigma_SB) Sigma Omega_K, evaluated with the given surface density."""
+    kappa0 = d.kappa_const * d.temperature_cgs ** 2    # kappa = kappa0 T^2, T in code units
+    omega = (d.G * d.hydro_center_mass / radii_med ** 3) ** 0.5
+    # Q+ = 9/4 Sigma nu Omega^2 = Q- = 2 sigma T^4 / (3/8 tau), tau = tau_factor / density_factor kappa Sigma
+    tau_fac = d.tau_factor / d.density_factor
+    return (27.0 / 64.0 * tau_fac * kappa0 * d.constant_viscosity / d.sigma_sb) ** 0.5 * sigma_code * omega
 
 
 def jupiter_bodies(d: B.Desc):

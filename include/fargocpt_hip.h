@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FCPT_ABI_VERSION 1
+#define FCPT_ABI_VERSION 2
 
 /* error codes */
 #define FCPT_OK 0
@@ -47,6 +47,8 @@ enum { FCPT_SPACING_ARITHMETIC = 0, FCPT_SPACING_LOGARITHMIC = 1, FCPT_SPACING_E
 enum { FCPT_EOS_ISOTHERMAL = 0, FCPT_EOS_IDEAL = 1 };
 enum { FCPT_ARTVISC_NONE = 0, FCPT_ARTVISC_TW = 1, FCPT_ARTVISC_SN = 2 };
 enum { FCPT_LIMITER_VANLEER = 0, FCPT_LIMITER_MC = 1 };
+enum { FCPT_OPACITY_LIN = 0, FCPT_OPACITY_BELL = 1, FCPT_OPACITY_CONST = 2, FCPT_OPACITY_SIMPLE = 3 };
+enum { FCPT_BETAREF_ZERO = 0, FCPT_BETAREF_REFERENCE = 1, FCPT_BETAREF_MODEL = 2, FCPT_BETAREF_FLOOR = 3 };
 enum { FCPT_INTEGRATOR_EULER = 0, FCPT_INTEGRATOR_LEAPFROG = 1 };
 /* per-variable boundary conditions (src/boundary_conditions/config.cpp:97-343) */
 enum {
@@ -182,6 +184,24 @@ typedef struct fcpt_desc {
     double disk_mass;                /* DiskMass */
     int32_t initialize_vradial_zero; /* InitializeVradialZero */
     int32_t initialize_pure_keplerian; /* InitializePureKeplerian */
+
+    /* cooling terms of SubStep3 (calculate_qminus, src/SourceEuler.cpp:931-950; ideal EOS only) */
+    int32_t cooling_surface; /* SurfaceCooling: thermal (src/SourceEuler.cpp:790-820) */
+    int32_t opacity;         /* Opacity (src/opacity.cpp): FCPT_OPACITY_*; Bell is not supported */
+    double cooling_radiative_factor; /* CoolingRadiativeFactor */
+    double kappa_const;              /* KappaConst (code units: L0^2 / M0) */
+    double kappa_factor;             /* KappaFactor */
+    double tau_factor;               /* TauFactor */
+    double tau_min;                  /* TauMin */
+    double density_factor;           /* DensityFactor */
+    int32_t cooling_beta;            /* CoolingBetaLocal (thermal_relaxation, src/SourceEuler.cpp:632-786) */
+    int32_t cooling_beta_reference;  /* CoolingBetaReference: FCPT_BETAREF_* */
+    double cooling_beta_value;       /* CoolingBeta */
+    double cooling_beta_ramp_up;     /* CoolingBetaRampUp (code time units) */
+    /* unit system, code -> cgs (src/units.cpp:158-185), for the tabulated opacity laws */
+    double temperature_cgs; /* K per code temperature unit */
+    double density_cgs;     /* g/cm^3 per code volume-density unit */
+    double opacity_cgs;     /* cm^2/g per code opacity unit */
 } fcpt_desc;
 
 /* Row ranges of a slab, exactly the integers of src/split.cpp:56-78. */

@@ -48,7 +48,7 @@ struct orc_ctx {
     double *pressure, *soundspeed, *scale_height, *viscosity, *temperature, *potential;
     double *sigma0, *vrad0, *vazi0, *energy0;
     double *qr, *qphi, *divv, *trr, *tpp, *trp /* vector */, *qplus, *qminus, *density_int;
-    double *tau_eff; /* stays 0: cooling is out of scope */
+    double *tau_eff; /* kappa_eff (compute.cpp:41-87); 0 without surface cooling */
     /* transport scratch (TransportEuler.cpp:32-50) */
     double *rmp, *rmm, *lp, *lm, *vres, *vmean, *work, *qrstar /* vector */, *densstar /* vector */,
         *tempshift, *dq;
@@ -554,6 +554,11 @@ int orc_create(const fcpt_desc *d, const double *radii, orc_ctx **out)
     if (d->struct_size != sizeof(fcpt_desc) || d->abi_version != FCPT_ABI_VERSION)
         return FCPT_EINVAL;
     if (d->stabilize_viscosity != 0 || !d->body_force_from_potential)
+        return FCPT_EINVAL;
+    if ((d->cooling_surface || d->cooling_beta) && d->eos != FCPT_EOS_IDEAL)
+        return FCPT_EINVAL;
+    if (d->cooling_surface && d->opacity != FCPT_OPACITY_LIN && d->opacity != FCPT_OPACITY_CONST &&
+        d->opacity != FCPT_OPACITY_SIMPLE)
         return FCPT_EINVAL;
     orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
     if (!c)
@@ -1490,9 +1495,143 @@ static void update_velocities_with_viscosity(orc_ctx *c, double dt)
 }
 
 /* SourceEuler.cpp:496-536 viscous_heating, :614-630 calculate_qplus, :931-950 calculate_qminus */
-static void calculate_qminus(orc_ctx *c)
+
+/* opacity.cpp:45-168 lin(): Lin & Papaloizou (1985) opacities, cgs in / cgs out */
+static double opacity_lin(double density, double temperature)
 {
-    memset(c->qminus, 0, sizeof(double) * (size_t)c->nr * c->nphi); /* all cooling terms off */
+    const double power1 = 4.44444444e-2, power2 = 2.381e-2, power3 = 2.267e-1;
+    const double t234 = 1.6e3, t456 = 5.7e3, t678 = 2.28e6;
+    const double ak1 = 2.e-4, ak2 = 2.e16, ak3 = 5.e-3;
+    const double bk3 = 50., bk4 = 2.e-2, bk5 = 2.e4, bk6 = 1.e4, bk7 = 1.5e10, bk8 = 0.348;
+    if (temperature > t234 * pow(density, power1)) {
+        const double ts4 = 1.e-4 * temperature;
+        const double density13 = pow(density, 1.0 / 3.0);
+        const double density23 = density13 * density13;
+        const double ts42 = ts4 * ts4;
+        const double ts44 = ts42 * ts42;
+        const double ts48 = ts44 * ts44;
+        if (temperature > t456 * pow(density, power2)) {
+            if ((temperature < t678 * pow(density, power3)) || (density <= 1e-10)) {
+                const double o5 = bk5 * density23 * ts42 * ts4;
+                const double o6 = bk6 * density13 * ts48 * ts42;
+                const double o7 = bk7 * density / (ts42 * sqrt(ts4));
+                const double o6an = o6 * o6, o7an = o7 * o7;
+                return pow(pow(o6an * o7an / (o6an + o7an), 2) +
+                               pow(o5 / (1.0 + pow(ts4 / (1.1 * pow(density, 0.04762)), 10.0)), 4.0),
+                           0.25);
+            } else {
+                const double o7 = bk7 * density / (ts42 * sqrt(ts4));
+                const double o8 = bk8;
+                const double o7an = o7 * o7, o8an = o8 * o8;
+                return pow(o7an * o7an + o8an * o8an, 0.25);
+            }
+        } else {
+            const double o3 = bk3 * ts4;
+            const double o4 = bk4 * density23 / (ts48 * ts4);
+            const double o5 = bk5 * density23 * ts42 * ts4;
+            const double o4an = pow(o4, 4), o3an = pow(o3, 4);
+            return pow((o4an * o3an / (o4an + o3an)) + pow(o5 / (1.0 + 6.561e-5 / ts48), 4), 0.25);
+        }
+    } else {
+        const double t2 = temperature * temperature;
+        const double t4 = t2 * t2;
+        const double t8 = t4 * t4;
+        const double t10 = t8 * t2;
+        const double o1 = ak1 * t2;
+        const double o2 = ak2 * temperature / t8;
+        const double o3 = ak3 * temperature;
+        const double o1an = o1 * o1, o2an = o2 * o2;
+        return pow(pow(o1an * o2an / (o1an + o2an), 2) + pow(o3 / (1 + 1.e22 / t10), 4), 0.25);
+    }
+}
+/* opacity.cpp:10-43 opacity(): code units in / code units out */
+static double opacity_of(const fcpt_desc *d, double density, double temperature)
+{
+    const double temperatureCGS = temperature * d->temperature_cgs;
+    const double densityCGS = density * d->density_cgs;
+    double rv;
+    switch (d->opacity) {
+    case FCPT_OPACITY_LIN: rv = opacity_lin(densityCGS, temperatureCGS) * (1.0 / d->opacity_cgs); break;
+    case FCPT_OPACITY_CONST: rv = d->kappa_const; break;
+    case FCPT_OPACITY_SIMPLE: rv = d->kappa_const * (temperatureCGS * temperatureCGS); break;
+    default: rv = 0.0; break;
+    }
+    return d->kappa_factor * rv;
+}
+/* compute.cpp:17-35 midplane_density + :41-87 kappa_eff at one cell: returns tau_eff */
+static double tau_eff_of(const fcpt_desc *d, double sigma, double H, double temperature)
+{
+    const double rho = sigma / (d->density_factor * H);
+    const double kappa = opacity_of(d, rho, temperature);
+    const double tau = d->tau_factor * (1.0 / d->density_factor) * kappa * sigma;
+    if (d->opacity == FCPT_OPACITY_SIMPLE)
+        return 3.0 / 8.0 * tau; /* D'Angelo et al. 2003 eq. (28) */
+    return 3.0 / 8.0 * tau + sqrt(3.0) / 4.0 + 1.0 / (4.0 * tau + d->tau_min);
+}
+/* SourceEuler.cpp:632-786 thermal_relaxation (beta cooling; the opacity-based Ziampras variants are
+ * not part of the path) */
+static void thermal_relaxation(orc_ctx *c, double current_time)
+{
+    const int Nr = c->nr - 1, Nphi = c->nphi;
+    const fcpt_desc *d = &c->d;
+#pragma omp parallel for if (c->big)
+    for (int nr = 1; nr < Nr; ++nr)
+        for (int naz = 0; naz < Nphi; ++naz) {
+            const double r = c->Rmed[nr];
+            const double omega_k = sqrt(d->G * d->hydro_center_mass / (r * r * r));
+            const double E = c->energy[IDX(c, nr, naz)];
+            const double t_ramp_up = d->cooling_beta_ramp_up;
+            double beta_inv = 1 / d->cooling_beta_value;
+            if (t_ramp_up > 0.0) {
+                const double x = 2 * current_time / t_ramp_up;
+                const double ramp_factor = 1 - exp(-(x * x));
+                beta_inv = beta_inv * ramp_factor;
+            }
+            double delta_E = E;
+            if (d->cooling_beta_reference == FCPT_BETAREF_REFERENCE) {
+                delta_E -= c->energy0[IDX(c, nr, naz)] / c->sigma0[IDX(c, nr, naz)] * c->sigma[IDX(c, nr, naz)];
+            } else if (d->cooling_beta_reference == FCPT_BETAREF_MODEL) {
+                const double E0 = 1.0 / (d->adiabatic_index - 1.0) * (d->aspect_ratio * d->aspect_ratio) *
+                                  pow(c->Rmed[nr], 2.0 * d->flaring_index - 1.0) * d->G * d->hydro_center_mass *
+                                  c->sigma[IDX(c, nr, naz)];
+                delta_E -= E0;
+            } else if (d->cooling_beta_reference == FCPT_BETAREF_FLOOR) {
+                const double minimum_energy =
+                    d->minimum_temperature * c->sigma[IDX(c, nr, naz)] / d->mu * d->Rgas / (d->adiabatic_index - 1.0);
+                delta_E -= minimum_energy;
+            }
+            c->qminus[IDX(c, nr, naz)] += delta_E * omega_k * beta_inv;
+        }
+}
+/* SourceEuler.cpp:790-820 thermal_cooling (SurfaceCooling: thermal) */
+static void thermal_cooling(orc_ctx *c)
+{
+    const int Nr = c->nr - 1, Nphi = c->nphi;
+    const fcpt_desc *d = &c->d;
+    /* midplane_density recomputes the scale height from the current sound speed (compute.cpp:19) */
+    compute_scale_height(c);
+#pragma omp parallel for if (c->big)
+    for (int nr = 0; nr < c->nr; ++nr)
+        for (int naz = 0; naz < Nphi; ++naz)
+            c->tau_eff[IDX(c, nr, naz)] = tau_eff_of(d, c->sigma[IDX(c, nr, naz)], c->scale_height[IDX(c, nr, naz)],
+                                                     c->temperature[IDX(c, nr, naz)]);
+#pragma omp parallel for if (c->big)
+    for (int nr = 1; nr < Nr; ++nr)
+        for (int naz = 0; naz < Nphi; ++naz) {
+            const double T = c->temperature[IDX(c, nr, naz)];
+            const double T2 = T * T, Tm2 = d->minimum_temperature * d->minimum_temperature;
+            const double T4 = T2 * T2, Tmin4 = Tm2 * Tm2;
+            c->qminus[IDX(c, nr, naz)] +=
+                d->cooling_radiative_factor * 2 * d->sigma_sb * (T4 - Tmin4) / c->tau_eff[IDX(c, nr, naz)];
+        }
+}
+static void calculate_qminus(orc_ctx *c, double current_time)
+{
+    memset(c->qminus, 0, sizeof(double) * (size_t)c->nr * c->nphi);
+    if (c->d.cooling_beta)
+        thermal_relaxation(c, current_time);
+    if (c->d.cooling_surface)
+        thermal_cooling(c);
 }
 static void calculate_qplus(orc_ctx *c)
 {
@@ -1528,11 +1667,11 @@ static double substep3_alpha(const orc_ctx *c, double H, double sigma, double en
     return 1.0 + 2.0 * H * 4.0 * c->d.sigma_sb / c->d.c_light * inv_pow4 * (energy * energy * energy);
 }
 /* SourceEuler.cpp:956-1051 SubStep3 */
-static void substep3(orc_ctx *c, double dt)
+static void substep3(orc_ctx *c, double current_time, double dt)
 {
     const int Nr = c->nr, Nphi = c->nphi;
     compute_temperature(c);
-    calculate_qminus(c);
+    calculate_qminus(c, current_time);
     calculate_qplus(c);
 #pragma omp parallel for if (c->big)
     for (int nr = 1; nr < Nr - 1; ++nr)
@@ -1566,7 +1705,17 @@ static void compute_heating_cooling_for_CFL(orc_ctx *c)
         return;
     update_viscosity(c);
     compute_viscous_stress_tensor(c);
-    calculate_qminus(c);
+    compute_temperature(c);
+    {
+        /* at this point of init_euler the reference copies (SIGMA0, ENERGY0) do not exist yet
+         * (copy_initial_values follows, init.cpp:337): the beta term relative to them is 0 */
+        const int ref = c->d.cooling_beta_reference;
+        const int beta = c->d.cooling_beta;
+        if (ref == FCPT_BETAREF_REFERENCE)
+            c->d.cooling_beta = 0;
+        calculate_qminus(c, c->clk.time);
+        c->d.cooling_beta = beta;
+    }
     calculate_qplus(c);
     const int Nr = c->nr - 1, Nphi = c->nphi;
     for (int nr = 1; nr < Nr; ++nr)
@@ -1999,7 +2148,7 @@ int orc_init_physics(orc_ctx *c)
 }
 
 /* the gas "kick" shared by both integrators (simulation.cpp:190-203 / :324-337 / :379-392) */
-static void gas_kick(orc_ctx *c, double dt)
+static void gas_kick(orc_ctx *c, double current_time, double dt)
 {
     /* update_with_sourceterms, SourceEuler.cpp:435-452 */
     momentum_update_radial(c, dt);
@@ -2010,7 +2159,7 @@ static void gas_kick(orc_ctx *c, double dt)
     compute_viscous_stress_tensor(c);
     update_velocities_with_viscosity(c, dt);
     if (c->d.eos == FCPT_EOS_IDEAL)
-        substep3(c, dt);
+        substep3(c, current_time, dt);
 }
 
 /* simulation.cpp:167-217 (step_Euler: potential .. Transport) and :316-393 (step_LeapFrog:
@@ -2022,7 +2171,7 @@ int orc_step(orc_ctx *c, double dt)
     if (c->d.integrator == FCPT_INTEGRATOR_LEAPFROG) {
         const double frog_dt = dt / 2;
         calculate_potential(c);
-        gas_kick(c, frog_dt);
+        gas_kick(c, c->clk.time, frog_dt); /* start_time (simulation.cpp:333) */
         apply_boundary_condition(c, 0.0, 0);
         Transport(c, dt);
         if (c->has_mid) { /* bodies at x_{i+1/2} */
@@ -2038,10 +2187,10 @@ int orc_step(orc_ctx *c, double dt)
             calculate_potential(c);
         }
         compute_pressure(c);
-        gas_kick(c, frog_dt);
+        gas_kick(c, c->clk.time + frog_dt, frog_dt); /* midstep_time (simulation.cpp:388) */
     } else {
         calculate_potential(c);
-        gas_kick(c, dt);
+        gas_kick(c, c->clk.time, dt);
         apply_boundary_condition(c, 0.0, 0);
         Transport(c, dt);
     }

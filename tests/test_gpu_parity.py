@@ -147,7 +147,7 @@ def test_weak_scaling_grid_four_slabs(product, oracle):
            ("sigma", "vrad", "vazi"))
 
 
-@pytest.mark.parametrize("adiabatic,nphi", [(False, 256), (True, 96), (False, 64)])
+@pytest.mark.parametrize("adiabatic,nphi", [(False, 256), (True, 96), (False, 64), (True, 320)])
 def test_leapfrog_integrator(product, oracle, adiabatic, nphi):
     """step_LeapFrog (src/simulation.cpp:276-459): kick 1/2, drift, kick 2/2 with the mid-step
     bodies; isothermal (marching source kernel and the narrow-grid fused path) and adiabatic."""
@@ -279,3 +279,36 @@ def test_disk_on_body_accel(product, oracle, adiabatic):
     for x, y in zip(a, b):
         assert np.all(np.abs(x - y) <= 1e-10 * np.abs(y).max() + 1e-12 * scale), (x, y)
         assert np.abs(y).max() > 0
+
+
+@pytest.mark.parametrize("case", ["surface_lin_march", "surface_simple_beta_reference_narrow", "beta_model_ramp_leapfrog",
+                                  "surface_const_beta_floor"])
+def test_cooling_terms(product, oracle, case):
+    """calculate_qminus in SubStep3 (SourceEuler.cpp:632-820,931-950): thermal
+    surface cooling with the Lin / Const / Simple opacities and beta cooling towards zero / the reference
+    state / the model profile / the floor, in the marching kernel (Nphi >= 128) and the per-cell kernels."""
+    nphi = 96 if "narrow" in case else 320
+    d = setups.planet_disk(product, 44, nphi, adiabatic=True)
+    d.heating_cooling_cfl_limit = 10.0
+    if case == "surface_lin_march":
+        d.cooling_surface, d.opacity = 1, B.OPACITY_LIN
+    elif case == "surface_simple_beta_reference_narrow":
+        d.cooling_surface, d.opacity, d.kappa_const = 1, B.OPACITY_SIMPLE, 17.77
+        d.tau_factor, d.density_factor = 1.0, 2.0
+        d.cooling_beta, d.cooling_beta_value, d.cooling_beta_reference = 1, 10.0, B.BETAREF_REFERENCE
+    elif case == "beta_model_ramp_leapfrog":
+        d.cooling_beta, d.cooling_beta_value, d.cooling_beta_reference = 1, 5.0, B.BETAREF_MODEL
+        d.cooling_beta_ramp_up = 0.05
+        d.integrator = B.INTEGRATOR_LEAPFROG
+    else:
+        d.cooling_surface, d.opacity, d.kappa_const = 1, B.OPACITY_CONST, 1.0e4
+        d.cooling_beta, d.cooling_beta_value, d.cooling_beta_reference = 1, 20.0, B.BETAREF_FLOOR
+    _check(run_pair(product, oracle, d, 25, bodies=setups.jupiter_bodies(d)), ("sigma", "vrad", "vazi", "energy"))
+
+
+def test_temperature_test_setup_parity(product, oracle):
+    """test/TemperatureTest/angelo.yml (100 x 2, leapfrog, viscous heating against thermal cooling with
+    kappa ~ T^2): 400 steps of the HIP path against the oracle, which passes the reference's own
+    criterion on this setup (tests/test_oracle_known_answers.py)."""
+    d = setups.temperature_test(product)
+    _check(run_pair(product, oracle, d, 400, amp=0.0), ("sigma", "vrad", "vazi", "energy"))

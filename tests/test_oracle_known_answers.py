@@ -98,3 +98,40 @@ def test_disk_on_body_accel_symmetries(product, oracle):
     sm = ctx.disk_on_body_accel(1.0, 0.0, 1.0, 0.3)
     assert abs(sm[0]) < abs(axi) and abs(sm[2]) < abs(axo)
     ctx.close()
+
+
+def test_temperature_test_reference_criterion(product, oracle):
+    """test/TemperatureTest (angelo.yml + check_results.py): a viscously heated disk cooling through
+    kappa = 2e-6 T^2 settles into T = sqrt(27/128 kappa nu / sigma_SB) Sigma Omega_K with
+    Sigma -> 300 sqrt(5 au / r) g/cm^2.  The reference's criterion, with its own constants: at snapshot
+    10 (t = 62 800) the azimuthally averaged temperature deviates by < 1 % for 2 < r < 15.  Pins the
+    oracle's SubStep3 cooling path (thermal surface cooling, Opacity: Simple, viscous heating, leapfrog)."""
+    from fargocpt_amd import driver, setups
+    d = setups.temperature_test(product)
+    ctx = driver.make_context(oracle, d)
+    S = driver.SlabSet([ctx])
+    S.prepare()
+    while ctx.clock.time < 62800.0 - 1e-9:
+        S.step()
+    radii = product.radii(d)
+    ri, rs = radii[:d.nr_global], radii[1:d.nr_global + 1]
+    r = 2.0 / 3.0 * (rs ** 3 - ri ** 3) / (rs ** 2 - ri ** 2)
+    sig, e = ctx.download(B.F_SIGMA), ctx.download(B.F_ENERGY)
+    ctx.close()
+    Tnum = (d.mu / d.Rgas * (d.adiabatic_index - 1.0) * e / sig).mean(axis=1) * 1.0756431684186062e+05
+    # --- check_results.py, verbatim ---
+    dens = 300 * np.sqrt(5 / r)
+    kappa = 2e-6
+    nu = 5e16  # cm2/s
+    sigma = 5.6704e-05  # erg cm^-2 s^-1 K^-4
+    l0 = 14959787070000
+    m0 = 1.98892e+33
+    Sigma0 = m0 / l0 / l0
+    G = 6.674e-8  # dyne cm^2/g^2
+    omega_k = np.sqrt(G * m0 * (r * l0) ** (-3))
+    Ttheo = np.sqrt(27 / 128 * kappa * nu / sigma) * dens * omega_k
+    Tdiff = np.abs(Tnum - Ttheo) / Ttheo
+    radial_range = np.logical_and(r > 2, r < 15)
+    assert np.max(Tdiff[radial_range]) < 0.01
+    densnum = sig.mean(axis=1) * Sigma0
+    assert np.max((np.abs(densnum - dens) / dens)[radial_range]) < 0.01
