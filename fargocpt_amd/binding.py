@@ -11,7 +11,7 @@ from typing import Optional
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OVERLAP = 7
 GEOM_PAD = 15
 MAX_BODIES = 8
