@@ -117,9 +117,10 @@ struct Config {
 const double G_CGS = 6.67430e-8, KB = 1.380649e-16, MU = 1.66053906660e-24;
 const double L0 = 1.495978707e13, M0 = 1.988409870698051e33;
 const double TEMP0 = G_CGS * MU / KB * M0 / L0;
+const double TIME0 = std::sqrt(L0 * L0 * L0 / (G_CGS * M0));
 
 // "<number> [unit]" -> code units for the quantity kind
-enum Kind { K_NONE, K_LEN, K_MASS, K_SIGMA, K_TEMP };
+enum Kind { K_NONE, K_LEN, K_MASS, K_SIGMA, K_TEMP, K_VISC };
 double number(const std::string &s, Kind kind)
 {
     std::istringstream is(s);
@@ -150,6 +151,9 @@ double number(const std::string &s, Kind kind)
     } else if (kind == K_TEMP) {
         if (u == "k")
             return v / TEMP0;
+    } else if (kind == K_VISC) {
+        if (u == "cm2/s")
+            return v / (L0 * L0 / TIME0);
     }
     fprintf(stderr, "fargocpt_hip: unit '%s' in '%s' not understood\n", u.c_str(), s.c_str());
     exit(2);
@@ -208,6 +212,11 @@ void config_to_desc(const Config &c, fcpt_desc &d)
         d.eos = FCPT_EOS_ISOTHERMAL; // Interpret.cpp:425-431
     d.mu = num(c, "mu", 1.0);
     d.aspect_ratio = num(c, "AspectRatio", 0.05);
+    {
+        const double t0 = num(c, "Temperature0", -1.0, K_TEMP); // Interpret.cpp:194-197
+        if (t0 > 0.0)
+            d.aspect_ratio = std::sqrt(t0 * d.Rgas / d.mu);
+    }
     d.flaring_index = num(c, "FlaringIndex", 0.0);
     d.minimum_temperature = num(c, "MinimumTemperature", 3.0 / TEMP0, K_TEMP);
     d.maximum_temperature = num(c, "MaximumTemperature", 1.0e300 / TEMP0, K_TEMP);
@@ -217,7 +226,7 @@ void config_to_desc(const Config &c, fcpt_desc &d)
     d.set_sigma0 = c.flag("SetSigma0", false);
     d.disk_mass = num(c, "DiskMass", 0.01, K_MASS);
     d.viscous_alpha = num(c, "ViscousAlpha", 0.0);
-    d.constant_viscosity = num(c, "ConstantViscosity", 0.0);
+    d.constant_viscosity = num(c, "ConstantViscosity", 0.0, K_VISC);
     d.radial_viscosity_factor = num(c, "RadialViscosityFactor", 1.0);
     d.stabilize_viscosity = (int)num(c, "StabilizeViscosity", 0);
     switch (std::tolower(c.str("ArtificialViscosity", "SN")[0])) {
@@ -229,6 +238,32 @@ void config_to_desc(const Config &c, fcpt_desc &d)
     d.artificial_viscosity_factor = num(c, "ArtificialViscosityFactor", 1.41);
     d.heating_viscous = c.flag("HeatingViscous", true);
     d.heating_viscous_factor = num(c, "HeatingViscousFactor", 1.0);
+    { // cooling terms (src/parameters.cpp:399-490,661-665)
+        const std::string sc = lower(c.str("SurfaceCooling", "No"));
+        if (sc == "thermal") {
+            d.cooling_surface = 1;
+        } else if (!(sc == "no" || sc == "off" || sc == "false")) {
+            fprintf(stderr, "fargocpt_hip: SurfaceCooling: %s is not supported\n", sc.c_str());
+            exit(2);
+        }
+        d.cooling_radiative_factor = num(c, "CoolingRadiativeFactor", 1.0);
+        const std::string op = lower(c.str("Opacity", "Lin"));
+        d.opacity = op == "lin" ? FCPT_OPACITY_LIN : op == "bell" ? FCPT_OPACITY_BELL : op == "const" ? FCPT_OPACITY_CONST
+                                                                                                       : FCPT_OPACITY_SIMPLE;
+        d.kappa_const = num(c, "KappaConst", 1.0);
+        d.kappa_factor = num(c, "KappaFactor", 1.0);
+        d.tau_factor = num(c, "TauFactor", 0.5);
+        d.tau_min = num(c, "TauMin", 0.01);
+        d.density_factor = num(c, "DensityFactor", std::sqrt(2.0 * M_PI));
+        d.cooling_beta = c.flag("CoolingBetaLocal", false);
+        d.cooling_beta_value = num(c, "CoolingBeta", 1.0);
+        d.cooling_beta_ramp_up = num(c, "CoolingBetaRampUp", 0.0);
+        const std::string br = lower(c.str("CoolingBetaReference", "Zero"));
+        d.cooling_beta_reference = br == "reference" ? FCPT_BETAREF_REFERENCE
+                                   : br == "model"   ? FCPT_BETAREF_MODEL
+                                   : br == "floor"   ? FCPT_BETAREF_FLOOR
+                                                     : FCPT_BETAREF_ZERO;
+    }
     d.fast_transport = std::tolower(c.str("Transport", "Fast")[0]) == 'f';
     const std::string lim = lower(c.str("FluxLimiter", "VanLeer"));
     d.flux_limiter = (lim == "mc" || lim == "m") ? FCPT_LIMITER_MC : FCPT_LIMITER_VANLEER;

@@ -77,3 +77,40 @@ def test_spreading_ring_setup_file(tmp_path):
     tau = 12 * 4.77e-5 * misc["time"] + 0.016
     theo = 1.0 / np.pi / tau / rc ** 0.25 * iv(0.25, 2.0 * rc / tau) * np.exp(-(1 + rc ** 2) / tau)
     assert np.mean(np.abs(sigma / theo - 1)) < SPREADING_RING_THRESHOLD
+
+
+def test_temperature_test_setup_file(tmp_path):
+    """test/TemperatureTest/angelo.yml through the driver on the GPU (577 k leapfrog steps of a 100 x 2
+    grid, ~2 minutes: launch-bound), checked as test/TemperatureTest/check_results.py checks it, with
+    that script's constants and threshold; the 1-D files it reads are azimuthal means of the 2-D ones."""
+    cfgtext = open(os.path.join(GOLDEN, "setups", "temperature_test_angelo.yml")).read()
+    cfg = tmp_path / "config.yml"
+    out = tmp_path / "tt"
+    lines = [("OutputDir: " + str(out)) if l.startswith("OutputDir") else l for l in cfgtext.splitlines()]
+    cfg.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([BIN, "-q", "start", str(cfg)], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr
+    out = str(out) + "/"
+    assert open(out + "snapshots/list.txt").read().split()[-1] == "10"
+    ri = np.genfromtxt(out + "used_rad.dat")
+    r = 2.0 / 3.0 * (ri[1:] ** 3 - ri[:-1] ** 3) / (ri[1:] ** 2 - ri[:-1] ** 2)
+    nr = len(r)
+    quant1 = np.fromfile(out + "snapshots/10/Temperature.dat").reshape(nr, -1).mean(1)
+    # --- check_results.py ---
+    dens = 300 * np.sqrt(5 / r)
+    kappa = 2e-6
+    nu = 5e16
+    sigma = 5.6704e-05
+    l0 = 14959787070000
+    m0 = 1.98892e+33
+    Sigma0 = m0 / l0 / l0
+    T0 = 1.0756431684186062e+05
+    G = 6.674e-8
+    omega_k = np.sqrt(G * m0 * (r * l0) ** (-3))
+    Ttheo = np.sqrt(27 / 128 * kappa * nu / sigma) * dens * omega_k
+    Tnum = quant1 * T0
+    Tdiff = np.abs(Tnum - Ttheo) / Ttheo
+    radial_range = np.logical_and(r > 2, r < 15)
+    assert np.max(Tdiff[radial_range]) < 0.01
+    densnum = np.fromfile(out + "snapshots/10/Sigma.dat").reshape(nr, -1).mean(1) * Sigma0
+    assert np.max((np.abs(densnum - dens) / dens)[radial_range]) < 0.01
