@@ -3296,9 +3296,11 @@ int launch_source_march(const Dev &P, hipStream_t st)
     if (const char *e = getenv("FCPT_SOURCE_ROWS")) // tuning knob
         rows = atoi(e) > 0 ? atoi(e) : rows;
     const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
-    int ring_sums = 0; // per-segment ring sums of v_phi for the transport's k_ring_mean (off: see launch_transport)
-    if (const char *e = getenv("FCPT_RING_PARTS"))
-        ring_sums = e[0] == '1' && segs <= P.ring_pstride;
+    // per-segment ring sums of v_phi, so that the transport's k_ring_mean reads 70 partials per ring
+    // instead of the ring itself
+    int ring_sums = segs <= P.ring_pstride;
+    if (const char *e = getenv("FCPT_SOURCE_RING_PARTS"))
+        ring_sums = ring_sums && e[0] != '0';
     const int chunks = (P.nr + 1 + rows - 1) / rows;
     const int waves = segs * chunks;
     const dim3 grid((waves + 3) / 4), block(256);
