@@ -2969,7 +2969,7 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
 #define CFL_MAXP 8
 template <bool ADI> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part)
 {
-    const int i = blockIdx.x;
+    const int i = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
     const int nphi = P.nphi, npair = nphi >> 1;
     const int t = threadIdx.x;
     const size_t row = (size_t)i * nphi;
