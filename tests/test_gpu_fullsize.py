@@ -1,0 +1,124 @@
+"""BASELINE.json's full sizes (2048 x 4096 and the 2048 x 6144 slab split), where the oracle is too slow
+to be the checker: size-independent properties of the path.
+
+* azimuthal symmetry: an axisymmetric disk without planet stays axisymmetric to rounding -- every
+  wavefront tile seam of the marching kernels and every integer shift of the FARGO transport would
+  show up as a phi-dependence;
+* rotation equivariance: rotating the initial perturbation by k cells rotates the result by k cells
+  (the tiles then cut the data elsewhere);
+* conservation: closed (reflecting) boundaries, no damping: the transport is in flux form, the disk
+  mass is conserved to rounding, and the angular momentum changes only through the viscous torque at the
+  walls (bounded far below the planet-free advection terms);
+* slab independence: 2 and 4 radial slabs with ghost exchange agree with the single slab (the reference
+  itself: 4e-13 between 1 and 2 ranks);
+* the device-resident time-step loop equals the host-driven loop."""
+import numpy as np
+import pytest
+
+from fargocpt_amd import binding as B, driver, setups
+from tests.util import perturb, rel_err
+
+pytestmark = pytest.mark.gpu
+NR, NPHI = 2048, 4096
+
+
+def _run(lib, d, fields, radii, nsteps, bodies=None, nslabs=1, device_loop=False):
+    ctxs = []
+    for rank in range(nslabs):
+        dd = d.copy()
+        dd.rank, dd.nranks = rank, nslabs
+        s = lib.split_domain(dd)
+        sub = tuple(np.ascontiguousarray(f[s.imin:s.imin + s.nr + (1 if k == 1 else 0)]) for k, f in enumerate(fields))
+        ctxs.append(driver.make_context(lib, dd, fields=sub, radii=radii, bodies=bodies))
+    S = driver.SlabSet(ctxs)
+    S.prepare()
+    if device_loop:
+        assert nslabs == 1
+        ctxs[0].run_steps(nsteps, snap=False)
+        dts = None
+    else:
+        dts = S.run(nsteps)
+    out = S.gather()
+    t = ctxs[0].clock.time
+    for c in ctxs:
+        c.close()
+    return out, dts, t
+
+
+@pytest.fixture(scope="module")
+def base(product):
+    d = setups.planet_disk(product, NR, NPHI)
+    d0 = d.copy()
+    radii = product.radii(d0)
+    fields = product.initial_fields(d0, radii)
+    return d0, radii, fields
+
+
+def test_axisymmetric_disk_stays_axisymmetric(product, base):
+    d, radii, fields = base
+    out, _, _ = _run(product, d, fields, radii, 30)
+    for k in ("sigma", "vrad", "vazi"):
+        a = out[k]
+        scale = np.abs(out["vazi"]).max() if k == "vrad" else np.abs(a).max()  # v_r itself is ~1e-5 v_phi
+        spread = np.abs(a - a[:, :1]).max() / scale
+        # the star's potential r^2 (cos^2 + sin^2) carries rounding noise in phi, which the upwind
+        # switches amplify a little; a seam or shift error would be of order 1e-3
+        assert spread <= 1e-11, (k, spread)
+
+
+def test_rotation_equivariance_and_device_loop(product, base):
+    d, radii, fields = base
+    bodies = None  # no planet: the problem is invariant under rotations by whole cells
+    f0 = perturb(fields, d, 1e-3)
+    ref, _, t_ref = _run(product, d, f0, radii, 20, bodies)
+    k = 1237  # not a multiple of any tile stride
+    f1 = tuple(np.roll(f, k, axis=1) for f in f0)
+    rot, _, _ = _run(product, d, f1, radii, 20, bodies)
+    for name in ("sigma", "vrad", "vazi"):
+        # (same phi-dependent rounding of the potential as above; v_r on the scale of v_phi)
+        scale = np.abs(ref["vazi"]).max() if name == "vrad" else np.abs(ref[name]).max()
+        assert np.abs(np.roll(rot[name], -k, axis=1) - ref[name]).max() / scale <= 1e-11, name
+    dev, _, t_dev = _run(product, d, f0, radii, 20, bodies, device_loop=True)
+    assert t_dev == t_ref
+    for name in ("sigma", "vrad", "vazi"):
+        assert np.array_equal(dev[name], ref[name]), name
+
+
+@pytest.mark.parametrize("adiabatic", [False, True])
+def test_mass_and_angular_momentum_closed_box(product, adiabatic):
+    d = setups.planet_disk(product, NR, NPHI, adiabatic=adiabatic, damping=False)
+    d0 = d.copy()
+    radii = product.radii(d0)
+    fields = perturb(product.initial_fields(d0, radii), d0, 1e-3)
+    ri, rs = radii[:NR], radii[1:NR + 1]
+    surf = np.pi * (rs ** 2 - ri ** 2) / NPHI
+    rmed = 2.0 / 3.0 * (rs ** 3 - ri ** 3) / (rs ** 2 - ri ** 2)
+
+    def totals(st):
+        # the closed box: rings 1 .. Nr-2 between the reflecting interfaces 1 and Nr-1 (the ghost rings
+        # 0 and Nr-1 are overwritten by the zero-gradient condition every step)
+        a = slice(1, NR - 1)
+        m = (st["sigma"][a] * surf[a, None]).sum()
+        l = (st["sigma"][a] * surf[a, None] * rmed[a, None] * (st["vazi"][a] + rmed[a, None] * d0.omega_frame)).sum()
+        return m, l
+
+    m0, l0 = totals({"sigma": fields[0], "vazi": fields[2]})
+    out, _, _ = _run(product, d0, fields, radii, 30, setups.jupiter_bodies(d0))
+    m1, l1 = totals(out)
+    assert abs(m1 / m0 - 1.0) <= 1e-13
+    # a Jupiter-mass planet exchanges angular momentum with the disk: a few 1e-8 of L per step at most
+    assert abs(l1 / l0 - 1.0) <= 1e-5
+
+
+@pytest.mark.parametrize("nphi,nslabs,adiabatic", [(4096, 2, False), (6144, 4, False), (3072, 2, True)])
+def test_radial_slabs_at_full_size(product, nphi, nslabs, adiabatic):
+    d = setups.planet_disk(product, NR if not adiabatic else 1024, nphi, adiabatic=adiabatic)
+    d0 = d.copy()
+    radii = product.radii(d0)
+    fields = perturb(product.initial_fields(d0, radii), d0, 1e-3)
+    bodies = setups.jupiter_bodies(d0)
+    one, dt1, _ = _run(product, d0, fields, radii, 12, bodies, 1)
+    many, dtn, _ = _run(product, d0, fields, radii, 12, bodies, nslabs)
+    assert np.allclose(dt1, dtn, rtol=1e-12, atol=0)
+    for k in ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ()):
+        assert rel_err(many[k], one[k]) <= 1e-12, k
