@@ -32,7 +32,7 @@ IC_PROFILE, IC_SPREADING_RING, IC_SHOCKTUBE = range(3)
  F_TEMPERATURE, F_POTENTIAL, F_SIGMA0, F_VRAD0, F_VAZI0, F_ENERGY0, F_QPLUS, F_QMINUS) = range(16)
 VECTOR_FIELDS = (F_VRAD, F_VRAD0)
 
-ERRORS = {-1: "FCPT_EINVAL", -2: "FCPT_ENOMEM", -3: "FCPT_EHIP", -4: "FCPT_ESPLIT", -5: "FCPT_ENODEV"}
+ERRORS = {-1: "FCPT_EINVAL", -2: "FCPT_ENOMEM", -3: "FCPT_EHIP", -4: "FCPT_ESPLIT", -5: "FCPT_ENODEV", -6: "FCPT_ESHEAR"}
 
 _i32, _u32, _u64, _f64 = C.c_int32, C.c_uint32, C.c_uint64, C.c_double
 

@@ -38,7 +38,11 @@ struct fcpt_ctx {
     bool profiling = false;
     bool fused_source = true;
     int src_parts = 0; // segments of ring sums left by the last k_source_march
-    bool kick_energy_b = false; // the last kick left the energy in energy_b (marching source step, ideal EOS)
+    bool kick_energy_b = false;
+    // the dt of the next step is the CFL policy's (set by calculate_timestep*, consumed by the step):
+    // with CFL <= 0.8 that keeps it inside the FARGO shear limit
+    bool policy_dt_dev = false;
+    double policy_dt_host = -1.0; // the last kick left the energy in energy_b (marching source step, ideal EOS)
     bool march_source = true;
     bool stepped = false; // fcpt_step ran since the last fcpt_post
     bool pressure_valid = false;
@@ -180,6 +184,11 @@ int read_clock(fcpt_ctx *c, DevClock *out)
     HIPCHK(hipMemcpyAsync(c->h_clk, c->P.clk, sizeof(DevClock), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = *c->h_clk;
+    if (out->shear_error) {
+        set_error("a step exceeded the FARGO shear limit (|Nshift[i]-Nshift[i-1]| > 1) without fallback kernels; "
+                  "the state is invalid (FCPT_TRANSPORT_FALLBACK=1 forces them)");
+        return FCPT_ESHEAR;
+    }
     return FCPT_OK;
 }
 
@@ -268,7 +277,7 @@ void enqueue_potential(fcpt_ctx *c, bool midstep)
 // the gas part of step_Euler up to Transport (simulation.cpp:167-217), or of step_LeapFrog
 // (simulation.cpp:316-393): kick 1/2 (dt/2), drift (dt), kick 2/2 (dt/2).  `dt_dev`: the step
 // length is already in the device clock (device-resident dt), else `dt` is written there.
-void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt)
+void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe)
 {
     const Dev &P = c->P;
     hipStream_t st = c->stream;
@@ -292,7 +301,7 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt)
     apply_boundary_view(c, Q, false);
     if (frog)
         launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step (saved in cfl_dt)
-    const TransportResult tr = launch_transport(Q, P, st);
+    const TransportResult tr = launch_transport(Q, P, shear_safe, st);
     c->P.cfl_ring_nparts = frog ? 0 : tr.cfl_parts; // leapfrog kicks v_phi once more
     if (!tr.marched)
         launch_clock_advance(P.clk, st);
@@ -813,8 +822,8 @@ int fcpt_synchronize(fcpt_ctx *c)
 {
     if (!c)
         return FCPT_EINVAL;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return FCPT_OK;
+    DevClock k;
+    return read_clock(c, &k); // synchronises, and reports a step beyond the shear limit
 }
 
 int fcpt_get_split(const fcpt_ctx *c, fcpt_split *out)
@@ -1033,6 +1042,7 @@ int fcpt_calculate_timestep_device(fcpt_ctx *c, const double *d_cfl_global)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
     launch_clock_policy_ptr(c->P.clk, c->d.cfl_max_var, d_cfl_global, c->stream);
+    c->policy_dt_dev = true;
     HIPCHK(hipGetLastError());
     return FCPT_OK;
 }
@@ -1042,7 +1052,8 @@ int fcpt_step_device(fcpt_ctx *c)
     if (!c)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    enqueue_step(c, true, 0.0);
+    enqueue_step(c, true, 0.0, c->policy_dt_dev && c->d.cfl <= 0.8);
+    c->policy_dt_dev = false;
     HIPCHK(hipGetLastError());
     return FCPT_OK;
 }
@@ -1066,6 +1077,7 @@ int fcpt_calculate_timestep(fcpt_ctx *c, double cfl_dt_global, double *dt)
     if (int rc = read_clock(c, &k))
         return rc;
     *dt = k.last_dt;
+    c->policy_dt_host = k.last_dt;
     return FCPT_OK;
 }
 
@@ -1092,7 +1104,8 @@ int fcpt_step(fcpt_ctx *c, double dt)
     if (!c)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    enqueue_step(c, false, dt);
+    enqueue_step(c, false, dt, c->policy_dt_host > 0.0 && dt <= c->policy_dt_host * (1.0 + 1e-12) && c->d.cfl <= 0.8);
+    c->policy_dt_host = -1.0;
     HIPCHK(hipGetLastError());
     return FCPT_OK;
 }
@@ -1217,7 +1230,7 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
         // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
         for (; n < nsteps; ++n) {
             launch_cfl(c->P, 1, c->P.cfl_ring_nparts > 0, c->stream); // CFL + CalculateTimeStep policy on the device
-            enqueue_step(c, true, 0.0);
+            enqueue_step(c, true, 0.0, c->d.cfl <= 0.8); // dt: the policy kernel of launch_cfl just above
             enqueue_post(c);
         }
         HIPCHK(hipGetLastError());

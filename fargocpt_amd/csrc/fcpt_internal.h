@@ -41,6 +41,8 @@ struct DevClock {
     unsigned long long n_hydro_iter;
     unsigned int n_monitor;
     unsigned int n_snapshot;
+    unsigned int shear_error; // sticky: k_transport_fused met |dNshift| > 1 in a step launched without fallback
+    unsigned int pad;
 };
 
 // Per-row damping description, built on the host (damping.cpp:311-427).

@@ -52,7 +52,7 @@ struct TransportResult {
     int cfl_parts; // > 0: per-tile ring sums of the new v_phi are in cfl_ring_part
     double *sigma, *energy, *vrad, *vazi;
 };
-TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st);
+TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st);
 void launch_substep3_cooling_only(const Dev &P, hipStream_t st);
 void launch_disk_on_body(const Dev &P, double x, double y, double r_object, double smoothing_fixed, double r_sm, double *out,
                          hipStream_t st);

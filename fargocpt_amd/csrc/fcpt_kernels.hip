@@ -2535,7 +2535,8 @@ __device__ __forceinline__ double damp_apply(double X, int type, double ef, cons
 }
 
 template <int C, bool ADI, bool DAMP, int LIM>
-__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int ring_sums)
+__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int ring_sums,
+                                                        int has_fallback)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     constexpr int LO = TfHalo<C>::lo, HI = TfHalo<C>::hi;
@@ -2565,8 +2566,11 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
             prev = cur;
         }
         if (jump) {
-            if (lane == 0)
+            if (lane == 0) {
                 *P.shift_jump = 1;
+                if (!has_fallback) // nothing behind this kernel will redo the step: report it
+                    W.clk->shear_error = 1;
+            }
             return;
         }
     }
@@ -3426,7 +3430,7 @@ static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, 
 #undef MARCHC
 #undef MARCHK
 
-TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st)
+TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     // Transport, TransportEuler.cpp:112-136
@@ -3457,11 +3461,17 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st)
         if (const char *e = getenv("FCPT_RING_PARTS"))
             ring_sums = e[0] == '1' && tiles <= P.ring_pstride;
         res.cfl_parts = ring_sums ? tiles : 0;
+        // shear_safe: dt comes from the CFL policy with CFL <= 0.8, so |Nshift[i] - Nshift[i-1]| <= 1 is
+        // guaranteed (cfl.cpp:207-220) and the two idle fallback launches (5 us) are not queued; a
+        // violation would still be detected and reported as FCPT_ESHEAR
+        int fallback = shear_safe ? 0 : 1;
+        if (const char *e = getenv("FCPT_TRANSPORT_FALLBACK"))
+            fallback = e[0] != '0';
 #define TFK(CC, AA, DD)                                                                                             \
     if (P.limiter == FCPT_LIMITER_MC)                                                                                \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, ring_sums); \
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, ring_sums, fallback); \
     else                                                                                                             \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, ring_sums)
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, ring_sums, fallback)
 #define TFC(CC)               \
     if (P.adiabatic) {        \
         if (W.damp_in_step)   \
@@ -3483,9 +3493,6 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st)
 #undef TFK
         // behind it, the two-kernel form: its blocks return at once unless the fused kernel met
         // |Nshift[i] - Nshift[i-1]| > 1 (a time step beyond the FARGO shear limit)
-        bool fallback = true;
-        if (const char *e = getenv("FCPT_TRANSPORT_FALLBACK"))
-            fallback = e[0] != '0';
         if (fallback) {
             launch_radial(P, P.shift_jump, st);
             launch_theta_march(P, Wm, 2, 0, 0, P.shift_jump, st);

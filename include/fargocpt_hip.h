@@ -34,6 +34,7 @@ extern "C" {
 #define FCPT_EHIP -3    /* a HIP runtime call failed */
 #define FCPT_ESPLIT -4  /* slab too narrow: needs >= 2*FCPT_OVERLAP rings (src/split.cpp:42-47) */
 #define FCPT_ENODEV -5  /* no HIP device */
+#define FCPT_ESHEAR -6  /* a step ran beyond the FARGO shear limit without its fallback (see fcpt_step) */
 
 /* src/constants.h:17-19 */
 #define FCPT_OVERLAP 7
@@ -349,6 +350,12 @@ int fcpt_snap_to_monitor(const fcpt_ctx *ctx, double cfl_dt, double *step_dt);
  * Transport.  Integrator: Leapfrog -- step_LeapFrog (src/simulation.cpp:316-393): gas kick 1/2 with
  * dt/2, boundary (final=false), Transport with dt, potential at mid-step, compute_pressure,
  * gas kick 2/2 with dt/2.  Asynchronous on the context's stream.  Advances time by dt. */
+ *
+ * The fused transport kernel relies on |Nshift[i] - Nshift[i-1]| <= 1, which the FARGO shear term of the
+ * CFL condition (src/cfl.cpp:207-220) guarantees for its own dt.  A dt that is not known to be the
+ * policy's (not <= the value fcpt_calculate_timestep returned last, or CFL > 0.8) gets the two-kernel
+ * transport queued behind as a device-side fallback, so any dt is computed correctly; if the limit is
+ * ever exceeded without that fallback, the next synchronising call returns FCPT_ESHEAR. */
 int fcpt_step(fcpt_ctx *ctx, double dt);
 
 /* CommunicateBoundaries, device side (src/commbound.cpp:108-125,163-180):

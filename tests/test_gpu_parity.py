@@ -240,16 +240,17 @@ def test_transport_beyond_shear_limit_falls_back(product, oracle, monkeypatch):
     """k_transport_fused couples rings i-1 and i through one lane shift, which covers
     |Nshift[i] - Nshift[i-1]| <= 1 (every dt inside the FARGO shear limit, cfl.cpp:207-220).  A step
     of 4x the CFL time step breaks that: the kernel must give up and the unfused kernels queued
-    behind it must produce the step -- and without them the result must be wrong, which shows the
-    situation did occur."""
+    behind it must produce the step.  (Steps whose dt is the CFL policy's with CFL <= 0.8 cannot get
+    there and skip the two idle launches.)"""
     d = setups.planet_disk(product, 48, 512)
     d.damping = 0
     d.first_dt = 1.0  # no 1.1x ramp: the first step already runs at the CFL limit
     bodies = setups.jupiter_bodies(d)
     _check(run_pair(product, oracle, d, 3, bodies=bodies, dt_scale=4.0), ("sigma", "vrad", "vazi"))
+    # without the fallback kernels the situation is detected and reported, not computed wrongly
     monkeypatch.setenv("FCPT_TRANSPORT_FALLBACK", "0")
-    (a, _), (b, _) = run_pair(product, oracle, d, 3, bodies=bodies, dt_scale=4.0)
-    assert rel_err(a["vrad"], b["vrad"]) > 1e-6 or not np.isfinite(a["vrad"]).all()
+    with pytest.raises(B.FcptError, match="FCPT_ESHEAR"):
+        run_pair(product, oracle, d, 3, bodies=bodies, dt_scale=4.0)
 
 
 @pytest.mark.parametrize("adiabatic", [False, True])
