@@ -349,7 +349,7 @@ int fcpt_snap_to_monitor(const fcpt_ctx *ctx, double cfl_dt, double *step_dt);
  * update_velocities_with_viscosity, SubStep3, apply_boundary_condition(final=false),
  * Transport.  Integrator: Leapfrog -- step_LeapFrog (src/simulation.cpp:316-393): gas kick 1/2 with
  * dt/2, boundary (final=false), Transport with dt, potential at mid-step, compute_pressure,
- * gas kick 2/2 with dt/2.  Asynchronous on the context's stream.  Advances time by dt. */
+ * gas kick 2/2 with dt/2.  Asynchronous on the context's stream.  Advances time by dt.
  *
  * The fused transport kernel relies on |Nshift[i] - Nshift[i-1]| <= 1, which the FARGO shear term of the
  * CFL condition (src/cfl.cpp:207-220) guarantees for its own dt.  A dt that is not known to be the
