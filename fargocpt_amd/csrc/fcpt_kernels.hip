@@ -105,6 +105,16 @@ __device__ __forceinline__ double fast_rcp1(double d)
     return fma(x, fma(-d, x, 1.0), x);
 }
 
+// 1/sqrt(x) from v_rsq_f64 (~2^-26) refined by two Newton steps (~1 ulp): a third of the issue cost of
+// sqrt followed by the IEEE division sequence
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
 __device__ __forceinline__ double dmin(double a, double b) { return b < a ? b : a; } // std::min
 __device__ __forceinline__ double dmax(double a, double b) { return a < b ? b : a; } // std::max
 
@@ -162,14 +172,18 @@ template <bool ROWU> __global__ void k_potential(const Dev P)
         const double dx = x - P.bx[k];
         const double dy = y - P.by[k];
         const double dist_2 = dx * dx + dy * dy;
-        const double d_smoothed = sqrt(dist_2 + smooth * smooth);
+        const double d2s = dist_2 + smooth * smooth;
+        const double inv_d = fast_rsqrt(d2s); // 1 / d_smoothed
         double klahr = 1.0;
         const double r_sm = P.brsm[k];
-        if (r_sm > 0.0 && d_smoothed < r_sm) {
-            const double q = d_smoothed / r_sm;
-            klahr = ((q * q) * (q * q) - 2.0 * (q * q * q) + 2.0 * d_smoothed / r_sm);
+        if (r_sm > 0.0) {
+            const double d_smoothed = d2s * inv_d;
+            if (d_smoothed < r_sm) {
+                const double q = d_smoothed / r_sm;
+                klahr = ((q * q) * (q * q) - 2.0 * (q * q * q) + 2.0 * d_smoothed / r_sm);
+            }
         }
-        pot += -P.G * P.bm[k] / d_smoothed * klahr;
+        pot += -P.G * P.bm[k] * inv_d * klahr;
     }
     pot += -P.indirect_x * x - P.indirect_y * y;
     P.potential[IDX(i, j)] = pot;
@@ -1081,7 +1095,9 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
 // Reads Sigma, Phi, v_r, v_phi, e once and writes v_r, v_phi, e, Q+, Q- once (10 doubles per
 // cell); the c_s / H / nu / T grids of the step are not written: fcpt_post recomputes them from
 // the final state, as recalculate_derived_disk_quantities does.
-template <int AV> // 0: none, 1: TW, 2: SN
+// COOL: the cooling terms of SubStep3 are compiled in (their opacity laws would otherwise cost the
+// common no-cooling case 70 registers: 134 -> 208 VGPRs)
+template <int AV, bool COOL> // AV 0: none, 1: TW, 2: SN
 __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs, int rows_per_chunk)
 {
     const int lane = threadIdx.x & 63;
@@ -1101,7 +1117,7 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     const double gm1 = P.gamma - 1.0;
     const double inv_sqrt_gamma = 1.0 / sqrt(P.gamma);
     const bool dissipate = P.art_visc_dissipation != 0;
-    const bool cooling = P.cooling_surface != 0 || P.cooling_beta != 0;
+    constexpr bool cooling = COOL;
 
 #define NEXT(x) lane_next(x) /* value of cell j+1 */
 #define PREV(x) lane_prev(x) /* value of cell j-1 */
@@ -3288,12 +3304,20 @@ int launch_source_march(const Dev &P, hipStream_t st)
         const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
         const int chunks = (P.nr + 1 + rows - 1) / rows;
         const dim3 grid((segs * chunks + 3) / 4), block(256);
-        if (P.art_visc == FCPT_ARTVISC_TW)
-            KLAUNCH(KID_SOURCE_MARCH, k_source_march_adi<1>, grid, block, P, segs, rows);
-        else if (P.art_visc == FCPT_ARTVISC_SN)
-            KLAUNCH(KID_SOURCE_MARCH, k_source_march_adi<2>, grid, block, P, segs, rows);
-        else
-            KLAUNCH(KID_SOURCE_MARCH, k_source_march_adi<0>, grid, block, P, segs, rows);
+        const bool cool = P.cooling_surface != 0 || P.cooling_beta != 0;
+#define ADIK(AV_)                                                                                 \
+    if (cool)                                                                                     \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, true>), grid, block, P, segs, rows);  \
+    else                                                                                          \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, false>), grid, block, P, segs, rows)
+        if (P.art_visc == FCPT_ARTVISC_TW) {
+            ADIK(1);
+        } else if (P.art_visc == FCPT_ARTVISC_SN) {
+            ADIK(2);
+        } else {
+            ADIK(0);
+        }
+#undef ADIK
         return -segs; // marched, no ring sums
     }
     int rows = 24; // measured at 2048x4096: 16 / 24 / 32 / 48 / 64 rings -> 0.133 / 0.132 / 0.141 / 0.152 / 0.188 ms
