@@ -109,3 +109,42 @@ def test_initial_fields_match_oracle(product, oracle, name):
 def test_kernel_name_table(product):
     names = product.kernel_names()
     assert "k_transport_radial" in names and len(set(names)) == len(names)
+
+
+def test_hot_kernel_occupancy_budget():
+    """The marching kernels are bound by the vector ALUs and by latency at 3-4 wavefronts per SIMD: their
+    register budget is part of the design.  Cross-compiles the kernels for gfx950
+    with -Rpass-analysis=kernel-resource-usage and checks occupancy and spills of the bench path."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fargocpt_amd", "csrc", "fcpt_kernels.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, src],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    usage, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z /\[\]]+): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1).strip()] = int(m.group(2))
+    budget = {  # mangled-name fragment -> minimum waves per SIMD
+        "k_transport_fusedILi1ELb0ELb1ELi0E": 4,   # isothermal, damping folded in, van Leer: the bench kernel
+        "k_transport_fusedILi1ELb1ELb1ELi0E": 3,   # ideal EOS
+        "14k_source_marchILi1E": 6,                # isothermal source step, TW artificial viscosity
+        "k_source_march_adiILi1ELb0E": 3,          # ideal EOS, no cooling terms compiled in
+        "k_cfl_ringsILb0E": 6,
+    }
+    for frag, waves in budget.items():
+        hits = [k for k in usage if frag in k]
+        assert hits, frag
+        u = usage[hits[0]]
+        assert u["Occupancy [waves/SIMD]"] >= waves, (frag, u)
+        assert u["VGPRs Spill"] == 0 and u["ScratchSize [bytes/lane]"] == 0, (frag, u)
