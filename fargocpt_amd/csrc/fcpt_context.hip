@@ -152,7 +152,6 @@ DampRange damp_range(const fcpt_ctx *c, int is_vector, int type, int outer)
 void apply_boundary_view(fcpt_ctx *c, const Dev &P, bool final, bool damping_done = false)
 {
     if (final && c->d.damping && !damping_done) {
-        c->P.cfl_ring_nparts = 0; // v_phi changes below: the ring sums left by the transport are stale
         // damping.cpp:754-774, order of damping_vector: vrad, vaz, sigma, energy
         for (int o = 0; o < 2; ++o)
             launch_damping(P, P.vrad, P.vrad0, P.Rinf.p, c->damp[0][o], 0, c->stream);
@@ -302,7 +301,6 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe)
     if (frog)
         launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step (saved in cfl_dt)
     const TransportResult tr = launch_transport(Q, P, shear_safe, st);
-    c->P.cfl_ring_nparts = frog ? 0 : tr.cfl_parts; // leapfrog kicks v_phi once more
     if (!tr.marched)
         launch_clock_advance(P.clk, st);
     // the marching transport is out of place: the new state may sit in the scratch twins
@@ -609,7 +607,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1) AL(shift_jump, 1)
     AL(cfl_part, (size_t)(nr + 256) * (size_t)((nphi + 255) / 256 + 1))
     P.ring_pstride = nphi / 32 + 4;
-    AL(ring_part, (size_t)nr * P.ring_pstride) AL(cfl_ring_part, (size_t)nr * P.ring_pstride)
+    AL(ring_part, (size_t)nr * P.ring_pstride)
 #undef AL
     if (!rc && hipHostMalloc((void **)&c->h_clk, sizeof(DevClock)) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -884,8 +882,6 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
     HIPCHK(hipStreamSynchronize(c->stream));
     if (f == FCPT_F_SCALE_HEIGHT)
         c->potential_valid = false;
-    if (f == FCPT_F_VAZI)
-        c->P.cfl_ring_nparts = 0;
     return FCPT_OK;
 }
 
@@ -1014,7 +1010,7 @@ int fcpt_cfl(fcpt_ctx *c, double *dt_local)
     if (!c || !dt_local)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    launch_cfl(c->P, 0, c->P.cfl_ring_nparts > 0, c->stream);
+    launch_cfl(c->P, 0, c->stream);
     HIPCHK(hipGetLastError());
     DevClock k;
     if (int rc = read_clock(c, &k))
@@ -1030,7 +1026,7 @@ int fcpt_cfl_device(fcpt_ctx *c, double *d_dt_local)
     if (!c || !d_dt_local)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    launch_cfl(c->P, 0, c->P.cfl_ring_nparts > 0, c->stream);
+    launch_cfl(c->P, 0, c->stream);
     launch_clock_export_cfl(c->P.clk, d_dt_local, c->stream);
     HIPCHK(hipGetLastError());
     return FCPT_OK;
@@ -1229,7 +1225,7 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
     if (!snap) {
         // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
         for (; n < nsteps; ++n) {
-            launch_cfl(c->P, 1, c->P.cfl_ring_nparts > 0, c->stream); // CFL + CalculateTimeStep policy on the device
+            launch_cfl(c->P, 1, c->stream); // CFL + CalculateTimeStep policy on the device
             enqueue_step(c, true, 0.0, c->d.cfl <= 0.8); // dt: the policy kernel of launch_cfl just above
             enqueue_post(c);
         }

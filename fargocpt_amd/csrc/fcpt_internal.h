@@ -165,11 +165,10 @@ struct Dev {
     int damp_in_step;
     CArrI nshift_c;
     double *cfl_part; // per-block maxima of the CFL reduction
-    // per-ring partial sums of v_phi left by the marching kernels (pstride entries per ring):
-    // ring_part by k_source_march (src_ring_nparts valid entries, 0 = not available),
-    // cfl_ring_part by k_transport_theta_march (cfl_ring_nparts)
-    double *ring_part, *cfl_ring_part;
-    int ring_pstride, src_ring_nparts, cfl_ring_nparts;
+    // per-ring partial sums of v_phi left by k_source_march for the transport's ring mean
+    // (pstride entries per ring, src_ring_nparts of them valid, 0 = not available)
+    double *ring_part;
+    int ring_pstride, src_ring_nparts;
     DevClock *clk;
     // split
     int zero_no_ghost, one_no_ghost_vr, max_no_ghost, maxmo_no_ghost_vr, first_active, active_size;

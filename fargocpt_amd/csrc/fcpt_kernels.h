@@ -49,7 +49,6 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
 // context's pointers accordingly.
 struct TransportResult {
     int marched;  // > 0: a marching kernel ran (new state complete, clock advanced)
-    int cfl_parts; // > 0: per-tile ring sums of the new v_phi are in cfl_ring_part
     double *sigma, *energy, *vrad, *vazi;
 };
 TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st);
@@ -63,7 +62,7 @@ void launch_substep3_after_fused(const Dev &P, hipStream_t st);
 void launch_derived(const Dev &P, hipStream_t st);
 void launch_pressure(const Dev &P, hipStream_t st);
 void launch_temperature(const Dev &P, hipStream_t st);
-void launch_cfl(const Dev &P, int apply_policy, int use_part, hipStream_t st);
+void launch_cfl(const Dev &P, int apply_policy, hipStream_t st);
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st);
 void launch_clock_scale_dt(DevClock *clk, int mode, double dt, double factor, hipStream_t st);
 void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st);

@@ -1801,8 +1801,7 @@ __global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, 
                        (i == P.nr - 1 && P.is_last && P.bc_vaz[1] != FCPT_BC_NONE) ||
                        (!P.is_first && i < FCPT_OVERLAP) || (!P.is_last && i >= P.nr - FCPT_OVERLAP);
     double acc = 0.0;
-    // (the CFL's partial sums are those of k_transport_fused: not valid when it gave up)
-    if (part && !ghost && !(with_shift == 0 && *P.shift_jump)) {
+    if (part && !ghost) {
         for (int n = lane; n < nparts; n += 64)
             acc += part[i * pstride + n];
     } else {
@@ -2551,8 +2550,7 @@ __device__ __forceinline__ double damp_apply(double X, int type, double ef, cons
 }
 
 template <int C, bool ADI, bool DAMP, int LIM>
-__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int ring_sums,
-                                                        int has_fallback)
+__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int has_fallback)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     constexpr int LO = TfHalo<C>::lo, HI = TfHalo<C>::hi;
@@ -2832,15 +2830,6 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                 }
                 out_on = true;
                 out_pair = pair_valid && __builtin_amdgcn_ballot_w64(jout[C - 1] != jout[0] + 1) == 0;
-                if (ring_sums) { // this tile's share of sum_j v_phi(i, j) for the CFL's <v_phi>
-                    double part = 0.0;
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        part += valid[c] ? o_va[c] : 0.0;
-                    part = wave_sum(part);
-                    if (lane == 63)
-                        W.cfl_ring_part[i * W.ring_pstride + tile] = part;
-                }
             }
             ns_prev = ns;
 #pragma unroll
@@ -3458,7 +3447,7 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     // Transport, TransportEuler.cpp:112-136
-    TransportResult res = {0, 0, W.sigma, W.energy, W.vrad, W.vazi};
+    TransportResult res = {0, W.sigma, W.energy, W.vrad, W.vazi};
     // ---- everything in one kernel (tiled rings only) ------------------------------------------
     int CF = P.nphi >= 256 ? 1 : 0; // 1 cell per lane: 3 waves per SIMD (2 cells: 284 VGPRs, 1 wave)
     if (const char *e = getenv("FCPT_TRANSPORT_FUSED")) { // 0: off, 1 / 2: cells per lane
@@ -3479,12 +3468,6 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
         const int tiles = (P.nphi + tstride - 1) / tstride;
         const int chunks = (P.nr + rows - 1) / rows;
         const dim3 grid((chunks * tiles + 3) / 4), block(256);
-        // per-tile ring sums of the new v_phi for the next CFL: measured 3 us slower per step than
-        // letting k_ring_mean re-read the grid (the reduction sits on the marching critical path): off
-        int ring_sums = 0;
-        if (const char *e = getenv("FCPT_RING_PARTS"))
-            ring_sums = e[0] == '1' && tiles <= P.ring_pstride;
-        res.cfl_parts = ring_sums ? tiles : 0;
         // shear_safe: dt comes from the CFL policy with CFL <= 0.8, so |Nshift[i] - Nshift[i-1]| <= 1 is
         // guaranteed (cfl.cpp:207-220) and the two idle fallback launches (5 us) are not queued; a
         // violation would still be detected and reported as FCPT_ESHEAR
@@ -3493,9 +3476,9 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
             fallback = e[0] != '0';
 #define TFK(CC, AA, DD)                                                                                             \
     if (P.limiter == FCPT_LIMITER_MC)                                                                                \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, ring_sums, fallback); \
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback); \
     else                                                                                                             \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, ring_sums, fallback)
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, fallback)
 #define TFC(CC)               \
     if (P.adiabatic) {        \
         if (W.damp_in_step)   \
@@ -3607,12 +3590,11 @@ void launch_disk_on_body(const Dev &P, double x, double y, double r_object, doub
     KLAUNCH(KID_POTENTIAL, k_disk_on_body_final, dim3(1), dim3(256), (const double *)P.cfl_part, (int)(grid.x * grid.y), out);
 }
 
-void launch_cfl(const Dev &P, int apply_policy, int use_part, hipStream_t st)
+void launch_cfl(const Dev &P, int apply_policy, hipStream_t st)
 {
     // one block per ring: mean and cells in one pass (even Nphi up to 512 * CFL_MAXP; the isothermal
     // viscosity and sound speed per ring, or the lazily derived ones of the ideal EOS)
-    bool rings = (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 512 * CFL_MAXP && (!P.adiabatic || P.lazy_derived) &&
-                 !use_part;
+    bool rings = (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 512 * CFL_MAXP && (!P.adiabatic || P.lazy_derived);
     if (const char *e = getenv("FCPT_CFL_RINGS"))
         rings = rings && e[0] != '0';
     if (rings) {
@@ -3623,8 +3605,7 @@ void launch_cfl(const Dev &P, int apply_policy, int use_part, hipStream_t st)
         KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
         return;
     }
-    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 0,
-            use_part ? (const double *)P.cfl_ring_part : (const double *)nullptr, P.cfl_ring_nparts, P.ring_pstride);
+    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 0, (const double *)nullptr, 0, P.ring_pstride);
     const int nrows = P.active_size - P.first_active;
     int nparts = 0;
     if (nrows > 0) {
