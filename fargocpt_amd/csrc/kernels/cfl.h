@@ -1,0 +1,276 @@
+// Part of fcpt_kernels.hip (one translation unit, namespace fcpt): CFL reduction and the device clock.
+// Not a stand-alone header: included once, in the order given there.
+
+// ---------------------------------------------------------------------------
+// cfl.cpp:185-376 condition_cfl.  k_ring_mean gives <v_phi>.  dt_cell = CFL / sqrt(sum of
+// the squared inverse limits) and both sqrt and the quotient are monotone, so
+// min_cells dt_cell == CFL / sqrt(max_cells sum): k_cfl_cells reduces the per-cell sums to one
+// maximum per block (no atomics); k_cfl_final folds the block maxima, applies sqrt and the
+// quotient once, and adds the per-ring FARGO shear limit (:207-220).
+#define CFL_ROWS 8
+// One thread owns a phi column and walks CFL_ROWS rings (v_r(i+1) of one ring is v_r(i) of the
+// next, so every value is loaded once); per-block maxima, no atomics.
+template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r0_ = P.first_active + (blockIdx.y * blockDim.y + threadIdx.y) * CFL_ROWS;
+    const int r0 = ROWU ? __builtin_amdgcn_readfirstlane(r0_) : r0_;
+    double s = 0.0;
+    if (j < P.nphi && r0 < P.active_size) {
+        const int jn = JNEXT;
+        const int r1 = r0 + CFL_ROWS < P.active_size ? r0 + CFL_ROWS : P.active_size;
+        const double lf = P.leapfrog ? 0.6 : 1.0;
+        const double C2 = P.art_visc_factor * P.art_visc_factor;
+        const double gg1 = P.gamma * (P.gamma - 1.0), inv_sqrt_gamma = 1.0 / sqrt(P.gamma);
+        const double inv_limit = 1.0 / P.heating_cooling_cfl_limit;
+        double vr0 = P.vrad[IDX(r0, j)];
+        for (int i = r0; i < r1; ++i) {
+            const double vr1 = P.vrad[IDX(i + 1, j)];
+            const double inv_dxr = P.InvDiffRsup[i];         // 1 / (Rsup - Rinf)
+            const double inv_dxa = P.InvRmed[i] * P.invdphi; // 1 / (Rmed dphi)
+            const double inv_cell = dmax(inv_dxr, inv_dxa);  // 1 / min(dxRadial, dxAzimuthal)
+            const double va = P.vazi[IDX(i, j)];
+            const double van = P.vazi[IDX(i, jn)];
+            const double vres = P.fast_transport ? va - P.vmean_c[i] : va;
+            // isothermal: c_s and the alpha viscosity are per-ring constants (set once at init)
+            double cs, nu;
+            if (P.adiabatic && P.lazy_derived) { // k_adi_cs_h + k_viscosity in registers
+                cs = sqrt(gg1 * P.energy[IDX(i, j)] * fast_rcp(P.sigma[IDX(i, j)]));
+                const double H = cs * inv_sqrt_gamma * P.g_inv_omk[i];
+                nu = P.alpha_viscosity ? P.alpha * H * cs : P.nu_const;
+            } else {
+                cs = P.adiabatic ? P.soundspeed[IDX(i, j)] : P.cs_ring[i];
+                nu = P.adiabatic ? P.viscosity[IDX(i, j)] : (P.alpha_viscosity ? P.nu_ring[i] : P.nu_const);
+            }
+            const double invdt1 = cs * inv_cell;
+            const double invdt2 = vr0 * inv_dxr;
+            const double invdt3 = vres * inv_dxa;
+            double invdt4;
+            if (P.art_visc == FCPT_ARTVISC_SN) {
+                double dvRadial = vr1 - vr0;
+                double dvAzimuthal = van - va;
+                dvRadial = dvRadial > 0.0 ? 0.0 : -dvRadial;
+                dvAzimuthal = dvAzimuthal > 0.0 ? 0.0 : -dvAzimuthal;
+                invdt4 = 4.0 * C2 * dmax(dvRadial * inv_dxr, dvAzimuthal * inv_dxa) * lf;
+            } else { // the TW formula is also used for ArtificialViscosity: None (cfl.cpp:292)
+                const double eps_rr = (vr1 - vr0) * P.InvDiffRsup[i];
+                const double eps_pp = P.InvRmed[i] * ((van - va) * P.invdphi + 0.5 * (vr1 + vr0));
+                const double mdiv_V = -dmin(eps_rr + eps_pp, 0.0);
+                invdt4 = 4.0 * C2 * mdiv_V * lf;
+            }
+            const double invdt5 = 4.0 * nu * (inv_cell * inv_cell) * lf;
+            double invdt6 = 0.0;
+            if (P.adiabatic) {
+                if (P.lazy_derived)
+                    invdt6 = inv_limit * fabs((P.qplus[IDX(i, j)] - P.qminus[IDX(i, j)]) * fast_rcp(P.energy[IDX(i, j)])) * lf;
+                else
+                    invdt6 = inv_limit * fabs((P.qplus[IDX(i, j)] - P.qminus[IDX(i, j)]) / P.energy[IDX(i, j)]) * lf;
+            }
+            s = dmax(s, invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 + invdt5 * invdt5 +
+                            invdt6 * invdt6);
+            vr0 = vr1;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        s = dmax(s, __shfl_down(s, off, 64));
+    __shared__ double s_w[4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if ((tid & 63) == 0)
+        s_w[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0)
+        part[blockIdx.y * gridDim.x + blockIdx.x] = dmax(dmax(s_w[0], s_w[1]), dmax(s_w[2], s_w[3]));
+}
+// Ring mean and per-cell limits in one pass: a block owns a ring, keeps its v_phi in registers
+// (CFL_MAXP pairs per thread), sums them (<v_phi>, cfl.cpp:196-205), then evaluates the cells of
+// the ring against that mean (:222-330) -- v_phi is read once instead of once by k_ring_mean and
+// once by k_cfl_cells.  One partial maximum per ring.
+#define CFL_MAXP 8
+template <bool ADI> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part)
+{
+    const int i = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
+    const int nphi = P.nphi, npair = nphi >> 1;
+    const int t = threadIdx.x;
+    const size_t row = (size_t)i * nphi;
+    D2 va[CFL_MAXP];
+    double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+    for (int n = 0; n < CFL_MAXP; ++n) {
+        const int p = t + n * 256;
+        va[n] = D2{0.0, 0.0};
+        if (p < npair)
+            va[n] = *(const D2 *)(P.vazi + row + 2 * p);
+    }
+#pragma unroll
+    for (int n = 0; n < CFL_MAXP; ++n) {
+        acc += va[n].x;
+        acc2 += va[n].y;
+    }
+    acc += acc2;
+    for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_down(acc, off, 64);
+    __shared__ double s_w[4], s_m[4];
+    if ((t & 63) == 0)
+        s_w[t >> 6] = acc;
+    __syncthreads();
+    const double mean = ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) / (double)nphi;
+    if (t == 0)
+        P.vmean[i] = mean;
+    double s = 0.0;
+    if (i >= P.first_active && i < P.active_size) {
+        const double lf = P.leapfrog ? 0.6 : 1.0;
+        const double C2 = P.art_visc_factor * P.art_visc_factor;
+        const double inv_dxr = P.InvDiffRsup[i];         // 1 / (Rsup - Rinf)
+        const double inv_rmed = P.InvRmed[i];
+        const double inv_dxa = inv_rmed * P.invdphi;     // 1 / (Rmed dphi)
+        const double inv_cell = dmax(inv_dxr, inv_dxa);  // 1 / min(dxRadial, dxAzimuthal)
+        const double gg1 = P.gamma * (P.gamma - 1.0), inv_sqrt_gamma = 1.0 / sqrt(P.gamma);
+        const double inv_limit = 1.0 / P.heating_cooling_cfl_limit;
+        const double inv_omk = ADI ? P.g_inv_omk[i] : 0.0;
+        const double cs_iso = ADI ? 0.0 : P.cs_ring[i];
+        const double nu_iso = ADI ? 0.0 : (P.alpha_viscosity ? P.nu_ring[i] : P.nu_const);
+        const double sub = P.fast_transport ? mean : 0.0;
+#pragma unroll
+        for (int n = 0; n < CFL_MAXP; ++n) {
+            const int p = t + n * 256;
+            if (p < npair) {
+                const int j = 2 * p;
+                const D2 r0 = *(const D2 *)(P.vrad + row + j), r1 = *(const D2 *)(P.vrad + row + nphi + j);
+                const double van1 = P.vazi[row + (j + 2 >= nphi ? 0 : j + 2)]; // v_phi of cell j+2
+                D2 e2 = {0.0, 0.0}, s2 = {1.0, 1.0}, qp = {0.0, 0.0}, qm = {0.0, 0.0};
+                if (ADI) {
+                    e2 = *(const D2 *)(P.energy + row + j);
+                    s2 = *(const D2 *)(P.sigma + row + j);
+                    qp = *(const D2 *)(P.qplus + row + j);
+                    qm = *(const D2 *)(P.qminus + row + j);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const double vr0 = c ? r0.y : r0.x, vr1 = c ? r1.y : r1.x;
+                    const double v = c ? va[n].y : va[n].x, van = c ? van1 : va[n].y;
+                    double cs = cs_iso, nu = nu_iso;
+                    if (ADI) { // k_adi_cs_h + k_viscosity in registers
+                        const double e = c ? e2.y : e2.x, sg = c ? s2.y : s2.x;
+                        cs = sqrt(gg1 * e * fast_rcp(sg));
+                        const double H = cs * inv_sqrt_gamma * inv_omk;
+                        nu = P.alpha_viscosity ? P.alpha * H * cs : P.nu_const;
+                    }
+                    const double invdt1 = cs * inv_cell;
+                    const double invdt2 = vr0 * inv_dxr;
+                    const double invdt3 = (v - sub) * inv_dxa;
+                    double invdt4;
+                    if (P.art_visc == FCPT_ARTVISC_SN) {
+                        double dvRadial = vr1 - vr0;
+                        double dvAzimuthal = van - v;
+                        dvRadial = dvRadial > 0.0 ? 0.0 : -dvRadial;
+                        dvAzimuthal = dvAzimuthal > 0.0 ? 0.0 : -dvAzimuthal;
+                        invdt4 = 4.0 * C2 * dmax(dvRadial * inv_dxr, dvAzimuthal * inv_dxa) * lf;
+                    } else { // the TW formula is also used for ArtificialViscosity: None (cfl.cpp:292)
+                        const double eps_rr = (vr1 - vr0) * inv_dxr;
+                        const double eps_pp = inv_rmed * ((van - v) * P.invdphi + 0.5 * (vr1 + vr0));
+                        const double mdiv_V = -dmin(eps_rr + eps_pp, 0.0);
+                        invdt4 = 4.0 * C2 * mdiv_V * lf;
+                    }
+                    const double invdt5 = 4.0 * nu * (inv_cell * inv_cell) * lf;
+                    double invdt6 = 0.0;
+                    if (ADI) {
+                        const double e = c ? e2.y : e2.x;
+                        invdt6 = inv_limit * fabs(((c ? qp.y : qp.x) - (c ? qm.y : qm.x)) * fast_rcp(e)) * lf;
+                    }
+                    s = dmax(s, invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 +
+                                    invdt5 * invdt5 + invdt6 * invdt6);
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        s = dmax(s, __shfl_down(s, off, 64));
+    if ((t & 63) == 0)
+        s_m[t >> 6] = s;
+    __syncthreads();
+    if (t == 0)
+        part[i] = dmax(dmax(s_m[0], s_m[1]), dmax(s_m[2], s_m[3]));
+}
+__global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *part, int nparts, int apply_policy)
+{
+    double smax = 0.0;
+    for (int n = threadIdx.x; n < nparts; n += blockDim.x)
+        smax = dmax(smax, part[n]);
+    // FARGO shear limit, rings 0|1 (:207-208) and the active rings (:213-220)
+    double dt = 1.0e300;
+    for (int n = threadIdx.x; n < P.active_size; n += blockDim.x) {
+        if (n == 0 || n >= P.first_active) {
+            const double denom = fabs(P.vmean[n] * P.InvRmed[n] - P.vmean[n + 1] * P.InvRmed[n + 1]) + 1.0e-100;
+            dt = dmin(dt, P.cfl * P.dphi / denom);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        smax = dmax(smax, __shfl_down(smax, off, 64));
+        dt = dmin(dt, __shfl_down(dt, off, 64));
+    }
+    __shared__ double s_s[16], s_d[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        s_s[wave] = smax;
+        s_d[wave] = dt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            smax = dmax(smax, s_s[w]);
+            dt = dmin(dt, s_d[w]);
+        }
+        if (nparts > 0)
+            dt = dmin(dt, P.cfl / sqrt(smax));
+        P.clk->cfl_bits = (unsigned long long)__double_as_longlong(dt);
+        if (apply_policy) { // sim::CalculateTimeStep (simulation.cpp:100-118) for single-slab device loops
+            const double a = P.cfl_max_var * P.clk->last_dt;
+            const double rv = dt < a ? dt : a;
+            P.clk->cfl_dt = rv;
+            P.clk->last_dt = rv;
+            P.clk->dt = rv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// clock kernels (single thread)
+__global__ void k_clock_set_dt(DevClock *clk, double dt) { clk->dt = dt; }
+// leapfrog sub-steps: mode 0: step <- dt (host value), mode 1: step <- clk->dt (device value),
+// mode 2: step <- the saved one; then clk->dt = factor * step.  The full step is parked in cfl_dt.
+__global__ void k_clock_scale_dt(DevClock *clk, int mode, double dt, double factor)
+{
+    if (mode == 0)
+        clk->cfl_dt = dt;
+    else if (mode == 1)
+        clk->cfl_dt = clk->dt;
+    clk->dt = mode == 2 && factor == 1.0 ? clk->cfl_dt : clk->cfl_dt * factor;
+}
+__global__ void k_clock_advance(DevClock *clk)
+{
+    clk->time += clk->dt;
+    clk->n_hydro_iter += 1;
+}
+__global__ void k_clock_export_cfl(const DevClock *clk, double *out)
+{
+    *out = __longlong_as_double((long long)clk->cfl_bits);
+}
+__global__ void k_clock_policy_ptr(DevClock *clk, double cfl_max_var, const double *cfl_global)
+{
+    const double cfl_dt = *cfl_global;
+    const double a = cfl_max_var * clk->last_dt;
+    const double rv = cfl_dt < a ? cfl_dt : a;
+    clk->cfl_dt = rv;
+    clk->last_dt = rv;
+    clk->dt = rv;
+}
+// sim::CalculateTimeStep (simulation.cpp:100-118): rv = min(CFLmaxVar*last_dt, cfl_dt)
+__global__ void k_clock_policy(DevClock *clk, double cfl_max_var, int use_device_cfl, double cfl_global)
+{
+    const double cfl_dt = use_device_cfl ? __longlong_as_double((long long)clk->cfl_bits) : cfl_global;
+    const double a = cfl_max_var * clk->last_dt;
+    const double rv = cfl_dt < a ? cfl_dt : a;
+    clk->cfl_dt = rv;
+    clk->last_dt = rv;
+    clk->dt = rv;
+}

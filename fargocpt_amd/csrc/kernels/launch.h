@@ -1,0 +1,481 @@
+// Part of fcpt_kernels.hip (one translation unit, namespace fcpt): kernel names, per-kernel HIP-event profiler, launchers.
+// Not a stand-alone header: included once, in the order given there.
+
+// ---------------------------------------------------------------------------
+// per-kernel HIP-event timing (fcpt_profile_start/stop)
+const char *const kKernelNames[KID_COUNT] = {
+    "k_potential", "k_source_vr", "k_source_va", "k_compression_heating", "k_tw_q", "k_tw_va", "k_tw_vr",
+    "k_sn_q", "k_sn_e", "k_sn_vr", "k_sn_va", "k_temperature_range", "k_adi_cs_h", "k_iso_cs_h",
+    "k_viscosity", "k_pressure", "k_temperature", "k_stress_diag", "k_stress_rphi", "k_visc_va",
+    "k_visc_vr", "k_qplus_qminus", "k_substep3", "k_boundary", "k_damping", "k_transport_radial",
+    "k_ring_mean", "k_transport_theta1", "k_transport_theta2", "k_velocities", "k_cfl_final",
+    "k_cfl_cells", "k_clock", "k_src_fused", "k_av_fused", "k_visc_fused", "k_source_march",
+    "k_transport_theta_fused", "k_transport_theta_march", "k_transport_fused"};
+
+thread_local Profiler *g_prof = nullptr;
+
+void Profiler::begin(int id, hipStream_t st)
+{
+    if (!((mask >> id) & 1ull) || used + 2 > (int)events.size())
+        return;
+    (void)hipEventRecord(events[used], st);
+    open_id = id;
+}
+void Profiler::end(int id, hipStream_t st)
+{
+    if (open_id != id)
+        return;
+    (void)hipEventRecord(events[used + 1], st);
+    ids.push_back(id);
+    used += 2;
+    open_id = -1;
+}
+
+#define KLAUNCH(id, kernel, grid, block, ...)                              \
+    do {                                                                   \
+        if (g_prof)                                                        \
+            g_prof->begin((id), st);                                       \
+        hipLaunchKernelGGL(kernel, (grid), (block), 0, st, __VA_ARGS__);   \
+        if (g_prof)                                                        \
+            g_prof->end((id), st);                                         \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// launchers
+#define LAUNCH2D(id, kernel, nrows, ...)                                             \
+    do {                                                                             \
+        if ((nrows) > 0) {                                                           \
+            const Launch2D l = launch2d((nrows), P.nphi);                            \
+            if (l.block.x >= 64)                                                     \
+                KLAUNCH(id, (kernel<true>), l.grid, l.block, __VA_ARGS__);           \
+            else                                                                     \
+                KLAUNCH(id, (kernel<false>), l.grid, l.block, __VA_ARGS__);          \
+        }                                                                            \
+    } while (0)
+#define LAUNCH2D_T(id, kernel, targ, nrows, ...)                                     \
+    do {                                                                             \
+        if ((nrows) > 0) {                                                           \
+            const Launch2D l = launch2d((nrows), P.nphi);                            \
+            if (l.block.x >= 64)                                                     \
+                KLAUNCH(id, (kernel<targ, true>), l.grid, l.block, __VA_ARGS__);     \
+            else                                                                     \
+                KLAUNCH(id, (kernel<targ, false>), l.grid, l.block, __VA_ARGS__);    \
+        }                                                                            \
+    } while (0)
+
+void launch_potential(const Dev &P, hipStream_t st) { LAUNCH2D(KID_POTENTIAL, k_potential, P.nr, P); }
+
+void launch_source(const Dev &P, hipStream_t st)
+{
+    // update_with_sourceterms, SourceEuler.cpp:435-452
+    LAUNCH2D(KID_SOURCE_VR, k_source_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
+    LAUNCH2D(KID_SOURCE_VA, k_source_va, P.max_no_ghost - P.zero_no_ghost, P);
+    if (P.adiabatic)
+        LAUNCH2D(KID_COMPRESSION, k_compression_heating, P.nr - 1, P);
+}
+
+void launch_artificial_viscosity(const Dev &P, hipStream_t st)
+{
+    // art_visc::update_with_artificial_viscosity, artificial_viscosity.cpp:11-26
+    if (P.art_visc == FCPT_ARTVISC_TW) {
+        LAUNCH2D(KID_TW_Q, k_tw_q, P.nr, P);
+        LAUNCH2D(KID_TW_VA, k_tw_va, P.nr - 2, P);
+        LAUNCH2D(KID_TW_VR, k_tw_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
+    } else if (P.art_visc == FCPT_ARTVISC_SN) {
+        LAUNCH2D(KID_SN_Q, k_sn_q, P.nr, P);
+        if (P.adiabatic && P.art_visc_dissipation)
+            LAUNCH2D(KID_SN_E, k_sn_e, P.max_no_ghost - P.zero_no_ghost, P);
+        LAUNCH2D(KID_SN_VR, k_sn_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
+        LAUNCH2D(KID_SN_VA, k_sn_va, P.max_no_ghost - P.zero_no_ghost, P);
+    }
+    if (P.adiabatic && P.art_visc_dissipation)
+        LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
+}
+
+void launch_recalculate_viscosity(const Dev &P, hipStream_t st)
+{
+    // recalculate_viscosity, SourceEuler.cpp:205-223 (AspectRatioMode 0)
+    if (P.adiabatic)
+        LAUNCH2D(KID_ADI_CS_H, k_adi_cs_h, P.nr, P);
+    if (P.alpha_viscosity && P.adiabatic)
+        LAUNCH2D(KID_VISCOSITY, k_viscosity, P.nr, P); // isothermal alpha-nu never changes after init
+}
+
+void launch_viscosity_field(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISCOSITY, k_viscosity, P.nr, P); }
+
+void launch_iso_cs_h(const Dev &P, const double *cs_ring, hipStream_t st)
+{
+    LAUNCH2D(KID_ISO_CS_H, k_iso_cs_h, P.nr, P, cs_ring);
+}
+
+void launch_source_fused(const Dev &P, hipStream_t st)
+{
+    LAUNCH2D(KID_SRC_FUSED, k_src_fused, P.nr + 1, P);
+    LAUNCH2D(KID_AV_FUSED, k_av_fused, P.nr + 1, P);
+}
+// whole source step in one marching pass (isothermal, Nphi >= 128); returns false if not applicable
+int launch_source_march(const Dev &P, hipStream_t st)
+{
+    if (P.nphi < 128)
+        return 0;
+    if (P.adiabatic) {
+        if (const char *e = getenv("FCPT_MARCH_SOURCE_ADI"))
+            if (e[0] == '0')
+                return 0;
+        int rows = 24;
+        if (const char *e = getenv("FCPT_SOURCE_ROWS")) // tuning knob
+            rows = atoi(e) > 0 ? atoi(e) : rows;
+        const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
+        const int chunks = (P.nr + 1 + rows - 1) / rows;
+        const dim3 grid((segs * chunks + 3) / 4), block(256);
+        const bool cool = P.cooling_surface != 0 || P.cooling_beta != 0;
+#define ADIK(AV_)                                                                                 \
+    if (cool)                                                                                     \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, true>), grid, block, P, segs, rows);  \
+    else                                                                                          \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, false>), grid, block, P, segs, rows)
+        if (P.art_visc == FCPT_ARTVISC_TW) {
+            ADIK(1);
+        } else if (P.art_visc == FCPT_ARTVISC_SN) {
+            ADIK(2);
+        } else {
+            ADIK(0);
+        }
+#undef ADIK
+        return -segs; // marched, no ring sums
+    }
+    int rows = 24; // measured at 2048x4096: 16 / 24 / 32 / 48 / 64 rings -> 0.133 / 0.132 / 0.141 / 0.152 / 0.188 ms
+    if (const char *e = getenv("FCPT_SOURCE_ROWS")) // tuning knob
+        rows = atoi(e) > 0 ? atoi(e) : rows;
+    const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
+    // per-segment ring sums of v_phi, so that the transport's k_ring_mean reads 70 partials per ring
+    // instead of the ring itself
+    int ring_sums = segs <= P.ring_pstride;
+    if (const char *e = getenv("FCPT_SOURCE_RING_PARTS"))
+        ring_sums = ring_sums && e[0] != '0';
+    const int chunks = (P.nr + 1 + rows - 1) / rows;
+    const int waves = segs * chunks;
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (P.art_visc == FCPT_ARTVISC_TW)
+        KLAUNCH(KID_SOURCE_MARCH, k_source_march<1>, grid, block, P, segs, rows, ring_sums);
+    else if (P.art_visc == FCPT_ARTVISC_SN)
+        KLAUNCH(KID_SOURCE_MARCH, k_source_march<2>, grid, block, P, segs, rows, ring_sums);
+    else
+        KLAUNCH(KID_SOURCE_MARCH, k_source_march<0>, grid, block, P, segs, rows, ring_sums);
+    return ring_sums ? segs : -segs; // < 0: marched, but no ring sums
+}
+void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_FUSED, k_visc_fused, P.nr + 1, P); }
+void launch_substep3_after_fused(const Dev &P, hipStream_t st)
+{
+    // SubStep3 (SourceEuler.cpp:956-1051) with Q+ already evaluated by k_visc_fused
+    LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P);
+    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr - 2, P, 1);
+    LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
+}
+
+void launch_stress(const Dev &P, hipStream_t st)
+{
+    LAUNCH2D(KID_STRESS_DIAG, k_stress_diag, P.nr, P);
+    LAUNCH2D(KID_STRESS_RPHI, k_stress_rphi, P.nr - 1, P);
+}
+
+void launch_viscous_update(const Dev &P, hipStream_t st)
+{
+    LAUNCH2D(KID_VISC_VA, k_visc_va, P.nr - 2, P);
+    LAUNCH2D(KID_VISC_VR, k_visc_vr, P.maxmo_no_ghost_vr - P.one_no_ghost_vr, P);
+}
+
+void launch_substep3_cooling_only(const Dev &P, hipStream_t st)
+{
+    // compute_heating_cooling_for_CFL at init (SourceEuler.cpp:1507-1547): Q+ = 0 (gas at rest), Q- / alpha
+    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr - 2, P, 0);
+}
+
+void launch_substep3(const Dev &P, int update_energy, hipStream_t st)
+{
+    // SubStep3, SourceEuler.cpp:956-1051 (update_energy = 1) or the Q+/Q- part of
+    // compute_heating_cooling_for_CFL, :1507-1547 (update_energy = 0)
+    if (update_energy)
+        LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P);
+    LAUNCH2D(KID_QPLUS, k_qplus_qminus, P.nr, P);
+    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr - 2, P, update_energy);
+    if (update_energy)
+        LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
+}
+
+void launch_boundary(const Dev &P, hipStream_t st)
+{
+    const int bs = 256;
+    KLAUNCH(KID_BOUNDARY, k_boundary, dim3((P.nphi + bs - 1) / bs), dim3(bs), P);
+}
+
+void launch_damping(const Dev &P, double *q, double *q0, const double *radius, const DampRange &r,
+                    int is_density, hipStream_t st)
+{
+    if (r.type == FCPT_DAMP_NONE || r.lo > r.hi)
+        return;
+    KLAUNCH(KID_DAMPING, k_damping, dim3(r.hi - r.lo + 1), dim3(256), P, q, q0, radius, r.lo, r.type, r.rlim,
+            r.redge, r.tau, is_density);
+}
+
+#define FALLBACK_BLOCKS 256 /* grid of the idle in-stream fallback kernels */
+// one radial sweep + ring means (T1-T4); only_if: see k_transport_radial
+static void launch_radial(const Dev &P, const int *only_if, hipStream_t st)
+{
+    const Launch2D l = launch2d((P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS, P.nphi);
+    const int gx = (int)l.grid.x, gy = (int)l.grid.y;
+    const dim3 grid(only_if && gx * gy > FALLBACK_BLOCKS ? FALLBACK_BLOCKS : gx * gy);
+    if (l.block.x >= 64)
+        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<true>, grid, l.block, P, only_if, gx, gy);
+    else
+        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, grid, l.block, P, only_if, gx, gy);
+}
+static void launch_shift_means(const Dev &P, hipStream_t st)
+{
+    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 1,
+            P.src_ring_nparts ? (const double *)P.ring_part : (const double *)nullptr, P.src_ring_nparts, P.ring_pstride);
+}
+#define MARCHK(CC, PP, AA, DD)                                                                                      \
+    KLAUNCH(KID_THETA_MARCH, (k_transport_theta_march<CC, AA, DD, PP>), grid, block, Wm, (const double *)P.vazi,   \
+            (const double *)P.vrad, inB, tiles, rows, advance, only_if, nvb)
+#define MARCHC(CC, PP)                   \
+    if (P.adiabatic) {                   \
+        if (Wm.damp_in_step)             \
+            MARCHK(CC, PP, true, true);  \
+        else                             \
+            MARCHK(CC, PP, true, false); \
+    } else {                             \
+        if (Wm.damp_in_step)             \
+            MARCHK(CC, PP, false, true); \
+        else                             \
+            MARCHK(CC, PP, false, false);\
+    }
+// azimuthal marching kernel on set B -> state grids of Wm; returns the tile count
+static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, int advance, const int *only_if,
+                              hipStream_t st)
+{
+    ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
+    const int tstride = 64 * C - (THETA_LO + THETA_HI);
+    const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
+    int rows = THETA_ROWS;
+    if (const char *e = getenv("FCPT_THETA_ROWS"))
+        rows = atoi(e) > 0 ? atoi(e) : rows;
+    const int chunks = (P.nr + rows - 1) / rows;
+    const int waves = chunks * tiles;
+    const int nvb = (waves + 3) / 4;
+    const dim3 grid(only_if && nvb > FALLBACK_BLOCKS ? FALLBACK_BLOCKS : nvb), block(256);
+    if (!periodic) { // tiled: 2 cells per lane (1, 4 and 6 were measured slower), DPP lane shifts
+        MARCHC(2, false)
+    } else if (C == 1) {
+        MARCHC(1, true)
+    } else if (C == 2) {
+        MARCHC(2, true)
+    } else {
+        MARCHC(4, true)
+    }
+    return tiles;
+}
+#undef MARCHC
+#undef MARCHK
+
+TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st)
+{
+    // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
+    // Transport, TransportEuler.cpp:112-136
+    TransportResult res = {0, W.sigma, W.energy, W.vrad, W.vazi};
+    // ---- everything in one kernel (tiled rings only) ------------------------------------------
+    int CF = P.nphi >= 256 ? 1 : 0; // 1 cell per lane: 3 waves per SIMD (2 cells: 284 VGPRs, 1 wave)
+    if (const char *e = getenv("FCPT_TRANSPORT_FUSED")) { // 0: off, 1 / 2: cells per lane
+        const int v = atoi(e);
+        CF = v == 0 ? 0 : ((v == 1 || v == 2) && P.nphi >= 128 * v ? v : CF);
+    }
+    if (CF) {
+        Dev Wm = W; // the marching kernels cannot work in place
+        Wm.sigma = W.sigA;
+        Wm.energy = W.eA;
+        Wm.vrad = P.vrad == W.vrad ? W.vrad_b : W.vrad;
+        Wm.vazi = P.vazi == W.vazi ? W.vazi_b : W.vazi;
+        launch_shift_means(P, st);
+        int rows = TF_ROWS;
+        if (const char *e = getenv("FCPT_TRANSPORT_ROWS"))
+            rows = atoi(e) > 0 ? atoi(e) : rows;
+        const int tstride = 64 * CF - (CF == 2 ? TfHalo<2>::lo + TfHalo<2>::hi : TfHalo<1>::lo + TfHalo<1>::hi);
+        const int tiles = (P.nphi + tstride - 1) / tstride;
+        const int chunks = (P.nr + rows - 1) / rows;
+        const dim3 grid((chunks * tiles + 3) / 4), block(256);
+        // shear_safe: dt comes from the CFL policy with CFL <= 0.8, so |Nshift[i] - Nshift[i-1]| <= 1 is
+        // guaranteed (cfl.cpp:207-220) and the two idle fallback launches (5 us) are not queued; a
+        // violation would still be detected and reported as FCPT_ESHEAR
+        int fallback = shear_safe ? 0 : 1;
+        if (const char *e = getenv("FCPT_TRANSPORT_FALLBACK"))
+            fallback = e[0] != '0';
+#define TFK(CC, AA, DD)                                                                                             \
+    if (P.limiter == FCPT_LIMITER_MC)                                                                                \
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback); \
+    else                                                                                                             \
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, fallback)
+#define TFC(CC)               \
+    if (P.adiabatic) {        \
+        if (W.damp_in_step)   \
+            TFK(CC, true, true);  \
+        else                  \
+            TFK(CC, true, false); \
+    } else {                  \
+        if (W.damp_in_step)   \
+            TFK(CC, false, true); \
+        else                  \
+            TFK(CC, false, false);\
+    }
+        if (CF == 2) {
+            TFC(2)
+        } else {
+            TFC(1)
+        }
+#undef TFC
+#undef TFK
+        // behind it, the two-kernel form: its blocks return at once unless the fused kernel met
+        // |Nshift[i] - Nshift[i-1]| > 1 (a time step beyond the FARGO shear limit)
+        if (fallback) {
+            launch_radial(P, P.shift_jump, st);
+            launch_theta_march(P, Wm, 2, 0, 0, P.shift_jump, st);
+        }
+        res.marched = tiles;
+        res.sigma = Wm.sigma, res.energy = Wm.energy, res.vrad = Wm.vrad, res.vazi = Wm.vazi;
+        return res;
+    }
+    launch_radial(P, nullptr, st);
+    launch_shift_means(P, st);
+    ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
+    ThetaOut outA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
+    ThetaSet inA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
+    ThetaOut outB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
+    // fused azimuthal sweep when a lane-chunk size fits the ring, else the two-pass kernels
+    int C = 0, periodic = 0;
+    for (int c : {1, 2, 4})
+        if (!C && P.nphi % c == 0 && P.nphi <= 64 * c && (c == 1 || P.nphi / c >= 1)) {
+            C = c;
+            periodic = 1;
+        }
+    if (!C && P.nphi > 64 * 2)
+        C = 2;
+    if (const char *e = getenv("FCPT_THETA_FUSED"))
+        if (e[0] == '0')
+            C = 0;
+    bool march = C != 0;
+    if (const char *e = getenv("FCPT_THETA_MARCH"))
+        march = march && e[0] != '0';
+    if (march) {
+        res.marched = launch_theta_march(P, W, C, periodic, 1, nullptr, st);
+    } else if (C) {
+        const int tstride = 64 * C - 2 * THETA_HALO;
+        const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
+        const int waves = P.nr * tiles;
+        const dim3 grid((waves + 3) / 4), block(256);
+#define FUSED(CC)                                                                                      \
+    if (P.adiabatic)                                                                                   \
+        KLAUNCH(KID_THETA_FUSED, (k_transport_theta_fused<CC, true>), grid, block, P, inB, outA, tiles, periodic); \
+    else                                                                                               \
+        KLAUNCH(KID_THETA_FUSED, (k_transport_theta_fused<CC, false>), grid, block, P, inB, outA, tiles, periodic);
+        if (C == 1) {
+            FUSED(1)
+        } else if (C == 2) {
+            FUSED(2)
+        } else {
+            FUSED(4)
+        }
+#undef FUSED
+        if (W.damp_in_step)
+            LAUNCH2D_T(KID_VELOCITIES, k_velocities, true, P.nr, W, inA, (const double *)P.vrad);
+        else
+            LAUNCH2D_T(KID_VELOCITIES, k_velocities, false, P.nr, W, inA, (const double *)P.vrad);
+    } else {
+        LAUNCH2D_T(KID_THETA1, k_transport_theta, 1, P.nr, P, inB, outA);
+        LAUNCH2D_T(KID_THETA2, k_transport_theta, 2, P.nr, P, inA, outB);
+        if (W.damp_in_step)
+            LAUNCH2D_T(KID_VELOCITIES, k_velocities, true, P.nr, W, inB, (const double *)P.vrad);
+        else
+            LAUNCH2D_T(KID_VELOCITIES, k_velocities, false, P.nr, W, inB, (const double *)P.vrad);
+    }
+    return res;
+}
+
+void launch_derived(const Dev &P, hipStream_t st)
+{
+    // recalculate_derived_disk_quantities, SourceEuler.cpp:225-249 (AspectRatioMode 0)
+    if (P.adiabatic) {
+        LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P);
+        LAUNCH2D(KID_ADI_CS_H, k_adi_cs_h, P.nr, P);
+        LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P);
+        if (P.alpha_viscosity)
+            LAUNCH2D(KID_VISCOSITY, k_viscosity, P.nr, P);
+    } else {
+        LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P);
+    }
+}
+
+void launch_pressure(const Dev &P, hipStream_t st) { LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P); }
+void launch_temperature(const Dev &P, hipStream_t st) { LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P); }
+
+void launch_disk_on_body(const Dev &P, double x, double y, double r_object, double smoothing_fixed, double r_sm, double *out,
+                         hipStream_t st)
+{
+    const int nrows = P.active_size - P.first_active;
+    const dim3 grid((P.nphi + 255) / 256, nrows > 0 ? (nrows + DOB_ROWS - 1) / DOB_ROWS : 1), block(256);
+    KLAUNCH(KID_POTENTIAL, k_disk_on_body, grid, block, P, x, y, r_object, smoothing_fixed, r_sm, P.cfl_part);
+    KLAUNCH(KID_POTENTIAL, k_disk_on_body_final, dim3(1), dim3(256), (const double *)P.cfl_part, (int)(grid.x * grid.y), out);
+}
+
+void launch_cfl(const Dev &P, int apply_policy, hipStream_t st)
+{
+    // one block per ring: mean and cells in one pass (even Nphi up to 512 * CFL_MAXP; the isothermal
+    // viscosity and sound speed per ring, or the lazily derived ones of the ideal EOS)
+    bool rings = (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 512 * CFL_MAXP && (!P.adiabatic || P.lazy_derived);
+    if (const char *e = getenv("FCPT_CFL_RINGS"))
+        rings = rings && e[0] != '0';
+    if (rings) {
+        if (P.adiabatic)
+            KLAUNCH(KID_CFL_CELLS, k_cfl_rings<true>, dim3(P.nr), dim3(256), P, P.cfl_part);
+        else
+            KLAUNCH(KID_CFL_CELLS, k_cfl_rings<false>, dim3(P.nr), dim3(256), P, P.cfl_part);
+        KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
+        return;
+    }
+    KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 0, (const double *)nullptr, 0, P.ring_pstride);
+    const int nrows = P.active_size - P.first_active;
+    int nparts = 0;
+    if (nrows > 0) {
+        const Launch2D l = launch2d((nrows + CFL_ROWS - 1) / CFL_ROWS, P.nphi);
+        nparts = (int)(l.grid.x * l.grid.y);
+        if (l.block.x >= 64)
+            KLAUNCH(KID_CFL_CELLS, k_cfl_cells<true>, l.grid, l.block, P, P.cfl_part);
+        else
+            KLAUNCH(KID_CFL_CELLS, k_cfl_cells<false>, l.grid, l.block, P, P.cfl_part);
+    }
+    KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, nparts, apply_policy);
+}
+
+void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st)
+{
+    KLAUNCH(KID_CLOCK, k_clock_export_cfl, dim3(1), dim3(1), (const DevClock *)clk, out);
+}
+void launch_clock_policy_ptr(DevClock *clk, double cfl_max_var, const double *cfl_global, hipStream_t st)
+{
+    KLAUNCH(KID_CLOCK, k_clock_policy_ptr, dim3(1), dim3(1), clk, cfl_max_var, cfl_global);
+}
+void launch_clock_scale_dt(DevClock *clk, int mode, double dt, double factor, hipStream_t st)
+{
+    KLAUNCH(KID_CLOCK, k_clock_scale_dt, dim3(1), dim3(1), clk, mode, dt, factor);
+}
+void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st)
+{
+    KLAUNCH(KID_CLOCK, k_clock_set_dt, dim3(1), dim3(1), clk, dt);
+}
+void launch_clock_advance(DevClock *clk, hipStream_t st)
+{
+    KLAUNCH(KID_CLOCK, k_clock_advance, dim3(1), dim3(1), clk);
+}
+void launch_clock_policy(DevClock *clk, double cfl_max_var, int use_device_cfl, double cfl_global,
+                         hipStream_t st)
+{
+    KLAUNCH(KID_CLOCK, k_clock_policy, dim3(1), dim3(1), clk, cfl_max_var, use_device_cfl, cfl_global);
+}

@@ -1,0 +1,501 @@
+// Part of fcpt_kernels.hip (one translation unit, namespace fcpt): the wave-marching source kernels (isothermal and ideal EOS).
+// Not a stand-alone header: included once, in the order given there.
+
+// ===========================================================================
+// Wave-marching source step (isothermal EOS): the whole chain
+//   S1+S2 -> artificial viscosity -> stress tensor -> viscous update
+// in ONE pass over memory.  A wavefront owns 64 consecutive phi cells (phi neighbours by
+// wavefront shuffle) and marches outward ring by ring; every intermediate (v after the
+// source terms, Q_rr/Q_pp, v after artificial viscosity, div v, tau_*) lives in a rolling
+// register window of 2-4 rings, so each input ring (Sigma, Phi, v_r, v_phi) is read once
+// and each output ring (v_r, v_phi) written once: 6 doubles per cell.
+// Stage lags for the newest loaded ring m:
+//   A  v1(m)            source terms                      (SourceEuler.cpp:325-428)
+//   B  Q(m-1)           TW / SN artificial pressure        (artificial_viscosity.cpp:48-77,165-189)
+//   C  v2(m-1)          artificial-viscosity update        (artificial_viscosity.cpp:90-139,220-248)
+//   D  tau_diag(m-2), tau_rphi(m-1)                        (viscosity.cpp:149-254)
+//   E  v3(m-2) -> out   viscous update                     (viscosity.cpp:368-421)
+// Lane validity erodes by one cell per phi-coupled stage: lanes 3..61 of a segment are
+// final, segments advance by MARCH_VALID = 59 cells.  A chunk of MARCH_ROWS output rings
+// needs 5 extra input rings of warm-up.
+#define MARCH_VALID 59
+#define MARCH_LO 3
+
+template <int AV> // 0: none, 1: TW, 2: SN
+__global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int chunk = wave / segs;
+    const int seg = wave - chunk * segs;
+    const int nr = P.nr, nphi = P.nphi;
+    const int k0 = chunk * rows_per_chunk;
+    if (k0 > nr)
+        return;
+    const int k1 = (k0 + rows_per_chunk < nr + 1) ? k0 + rows_per_chunk : nr + 1; // v_r has rows 0..nr
+    const int jraw = seg * MARCH_VALID - MARCH_LO + lane;
+    const int j = jraw < 0 ? jraw + nphi : (jraw >= nphi ? jraw - nphi : jraw);
+    const bool store_lane = lane >= MARCH_LO && lane < MARCH_LO + MARCH_VALID && jraw < nphi;
+    const double dt = P.clk->dt;
+    const double C2 = P.art_visc_factor * P.art_visc_factor;
+
+#define NEXT(x) lane_next(x) /* value of cell j+1 */
+#define PREV(x) lane_prev(x) /* value of cell j-1 */
+    auto crow = [nr](int r) { return r < 0 ? 0 : (r > nr - 1 ? nr - 1 : r); };   // cell rows
+    auto vrow = [nr](int r) { return r < 0 ? 0 : (r > nr ? nr : r); };           // v_r rows
+
+    // rolling state (suffix _1.._3 = rings m-1..m-3)
+    double S_m = 0, S_1 = 0, S_2 = 0, S_3 = 0, Sp_m = 0, Sp_1 = 0, Sp_2 = 0; // Sigma and Sigma(j-1)
+    double F_m = 0, F_1 = 0;                                               // potential
+    double va0_m = 0, va0_1 = 0, va0n_m = 0, va0n_1 = 0;                   // v_phi (input) and (j+1)
+    double vr1_m = 0, vr1_1 = 0, va1_m = 0, va1_1 = 0;                      // after source terms
+    double qr_1 = 0, qr_2 = 0, qp_1 = 0, qp_2 = 0;                          // Q_rr/Q_pp (TW) or q_r/q_phi (SN)
+    double vr2_1 = 0, vr2_2 = 0, va2_1 = 0, va2_2 = 0;                      // after artificial viscosity
+    double trr_2 = 0, trr_3 = 0, tpp_2 = 0, tpp_3 = 0, trp_1 = 0, trp_2 = 0;
+
+    // ring k0-3 is the "previous" ring of the first iteration
+    {
+        const int r = crow(k0 - 3);
+        S_m = P.sigma[IDX(r, j)];
+        F_m = P.potential[IDX(r, j)];
+        va0_m = P.vazi[IDX(r, j)];
+        Sp_m = PREV(S_m);
+        va0n_m = NEXT(va0_m);
+    }
+    // software prefetch of the next input ring
+    int rn = k0 - 2;
+    double pS = P.sigma[IDX(crow(rn), j)], pF = P.potential[IDX(crow(rn), j)];
+    double pVa = P.vazi[IDX(crow(rn), j)], pVr = P.vrad[IDX(vrow(rn), j)];
+
+    for (int m = k0 - 2; m <= k1 + 1; ++m) {
+        const SrcRow R = crow_load(P.src_tab, m + 2); // every per-ring factor of this iteration, one batch
+        // ---- shift the window, take the prefetched ring m, prefetch ring m+1 ------------
+        S_3 = S_2; S_2 = S_1; S_1 = S_m; Sp_2 = Sp_1; Sp_1 = Sp_m;
+        F_1 = F_m;
+        va0_1 = va0_m; va0n_1 = va0n_m;
+        vr1_1 = vr1_m; va1_1 = va1_m;
+        S_m = pS; F_m = pF; va0_m = pVa;
+        const double vr0_m = pVr;
+        {
+            const int r = m + 1;
+            pS = P.sigma[IDX(crow(r), j)];
+            pF = P.potential[IDX(crow(r), j)];
+            pVa = P.vazi[IDX(crow(r), j)];
+            pVr = P.vrad[IDX(vrow(r), j)];
+        }
+        Sp_m = PREV(S_m);
+        va0n_m = NEXT(va0_m);
+        const double Fp_m = PREV(F_m);
+
+        // ---- A: source terms on ring m ---------------------------------------------------
+        {
+            const int r = m;
+            const double P_m = S_m * R.cs2_m, P_1 = S_1 * R.cs2_m1, Pp_m = Sp_m * R.cs2_m;
+            vr1_m = vr0_m;
+            if (r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr) {
+                double gradp = 2.0 * fast_rcp(S_m + S_1);
+                gradp *= (P_m - P_1);
+                gradp *= R.idr_m;
+                const double gradphi = (F_m - F_1) * R.idr_m;
+                const double vsum = va0_m + va0n_m + va0_1 + va0n_1;
+                const double vt = 0.25 * vsum + R.rinf_om_m;
+                const double vt2 = vt * vt;
+                vr1_m = vr0_m + dt * (-gradp - gradphi + vt2 * R.inv_rinf_m);
+            }
+            va1_m = va0_m;
+            if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
+                const double invdxtheta = R.inv_dxt_m; // 2 / (dphi (Rsup + Rinf))
+                const double gradp = 2.0 * fast_rcp(S_m + Sp_m) * (P_m - Pp_m) * invdxtheta;
+                const double gradphi = (F_m - Fp_m) * invdxtheta;
+                va1_m = va0_m + dt * (-gradp - gradphi);
+            }
+        }
+        // ---- B: artificial pressure on ring m-1 ------------------------------------------
+        qr_2 = qr_1; qp_2 = qp_1;
+        {
+            const double va1n_1 = NEXT(va1_1);
+            if (AV == 1) {
+                const double eps_rr = (vr1_m - vr1_1) * R.inv_drsup_b;
+                const double eps_pp = R.inv_rmed_b * ((va1n_1 - va1_1) * P.invdphi + 0.5 * (vr1_m + vr1_1));
+                const double div_V = dmin(eps_rr + eps_pp, 0.0);
+                const double l_sq = R.lsq_b;
+                qr_1 = l_sq * S_1 * -div_V * (eps_rr - 1.0 / 3.0 * div_V);
+                qp_1 = l_sq * S_1 * -div_V * (eps_pp - 1.0 / 3.0 * div_V);
+            } else if (AV == 2) {
+                const double dv_r = vr1_m - vr1_1;
+                qr_1 = dv_r < 0.0 ? C2 * S_1 * (dv_r * dv_r) : 0.0;
+                const double dv_phi = va1n_1 - va1_1;
+                qp_1 = dv_phi < 0.0 ? C2 * S_1 * (dv_phi * dv_phi) : 0.0;
+            }
+        }
+        // ---- C: artificial-viscosity update of ring m-1 -----------------------------------
+        vr2_2 = vr2_1; va2_2 = va2_1;
+        {
+            const int r = m - 1;
+            vr2_1 = vr1_1;
+            va2_1 = va1_1;
+            const bool upd_vr = r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr;
+            if (AV == 1) {
+                const double qpp_p = PREV(qp_1);
+                if (r >= 1 && r < nr - 1) {
+                    const double sigma_phi_avg = 0.5 * (S_1 + Sp_1);
+                    va2_1 = va1_1 + 2.0 * dt * (R.inv_rsum_c * fast_rcp(sigma_phi_avg)) * (qp_1 - qpp_p) * P.invdphi;
+                }
+                if (upd_vr) {
+                    const double sigma_r_avg = 0.5 * (S_1 + S_2);
+                    const double rm = R.rmed_c, rmm = R.rmed_cm1;
+                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt * fast_rcp(sigma_r_avg) * 2.0 * R.inv_drmed2_c *
+                                        ((qr_1 * rm - qr_2 * rmm) - 0.5 * (qp_1 + qp_2) * (rm - rmm));
+                }
+            } else if (AV == 2) {
+                const double qphi_p = PREV(qp_1);
+                if (upd_vr)
+                    vr2_1 = vr1_1 - dt * 2.0 * fast_rcp(S_1 + S_2) * (qr_1 - qr_2) * R.idr_c;
+                if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
+                    const double invdxtheta = R.inv_dxtheta_c;
+                    va2_1 = va1_1 - dt * 2.0 * fast_rcp(S_1 + Sp_1) * (qp_1 - qphi_p) * invdxtheta;
+                }
+            }
+        }
+        // ---- D: stress tensor: diagonal on ring m-2, r-phi on ring m-1 --------------------
+        trr_3 = trr_2; tpp_3 = tpp_2; trp_2 = trp_1;
+        {
+            const double va2n_2 = NEXT(va2_2);
+            const double dva = va2n_2 - va2_2;
+            const double divv =
+                (vr2_1 * R.rinf_d1 - vr2_2 * R.rinf_d0) * R.inv_drsuprb_d + dva * P.invdphi * R.inv_rmed_d;
+            const double nu = R.nu_d;
+            const double drr = (vr2_1 - vr2_2) * R.inv_drsup_d;
+            trr_2 = 2.0 * nu * S_2 * (drr - 1.0 / 3.0 * divv);
+            const double dpp = dva * P.invdphi * R.inv_rmed_d + 0.5 * (vr2_1 + vr2_2) * R.inv_rmed_d;
+            tpp_2 = 2.0 * nu * S_2 * (dpp - 1.0 / 3.0 * divv);
+        }
+        {
+            const int r = m - 1;
+            const double vr2p_1 = PREV(vr2_1);
+            trp_1 = 0.0;
+            if (r >= 1 && r <= nr - 1) {
+                const double dvazirdr = (va2_1 * R.inv_rmed_r - va2_2 * R.inv_rmed_rm1) * R.idr_r;
+                const double dvrdphi = (vr2_1 - vr2p_1) * P.invdphi;
+                const double drp = R.rinf_r * dvazirdr + dvrdphi * R.inv_rinf_r;
+                const double nu = R.nu_avg_r;
+                const double sigma = 0.25 * (S_1 + S_2 + Sp_1 + Sp_2);
+                trp_1 = nu * sigma * drp;
+            }
+        }
+        // ---- E: viscous update of ring k = m-2 and store ----------------------------------
+        {
+            const int k = m - 2;
+            const double tpp_p = PREV(tpp_2);
+            const double trp_n = NEXT(trp_2);
+            if (k >= k0 && k < k1) {
+                double vr3 = vr2_2, va3 = va2_2;
+                if (k >= 1 && k < nr - 1) {
+                    const double sigma_avg = 0.5 * (S_2 + Sp_2);
+                    va3 = va2_2 + dt * R.inv_rmed_k * fast_rcp(sigma_avg) *
+                                      (R.two_inv_dra2_k * (R.ra1sq_k * trp_1 - R.ra0sq_k * trp_2) +
+                                       (tpp_2 - tpp_p) * P.invdphi);
+                }
+                if (k >= P.one_no_ghost_vr && k < P.maxmo_no_ghost_vr) {
+                    const double sigma_avg = 0.5 * (S_2 + S_3);
+                    vr3 = vr2_2 + dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
+                                      ((R.rmed_k * trr_2 - R.rmed_km1 * trr_3) * R.idr_k +
+                                       (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
+                }
+                if (store_lane) {
+                    P.vrad_b[IDX(k, j)] = vr3;
+                    if (k < nr)
+                        P.vazi_b[IDX(k, j)] = va3;
+                }
+                if (ring_sums && k < nr) { // this segment's share of sum_j v_phi(k, j) for the transport's <v_phi>
+                    const double part = wave_sum(store_lane ? va3 : 0.0);
+                    if (lane == 63)
+                        P.ring_part[k * P.ring_pstride + seg] = part;
+                }
+            }
+        }
+    }
+#undef NEXT
+#undef PREV
+}
+
+// ===========================================================================
+// The same march for the energy equation (EquationOfState: ideal).  On top of k_source_march:
+//   A   pressure P = (gamma-1) e                                     (SourceEuler.cpp:1442-1473)
+//   S3  compression heating of ring m-1 with the velocities of A        (:459-493)
+//   B   dissipation of the artificial viscosity into e, temperature floor/ceiling
+//                                                                     (artificial_viscosity.cpp:79-88,191-218)
+//   V0  c_s, H and the alpha viscosity of ring m-1 from the new e       (:1054-1092,1218-1251, viscosity.cpp:98-137)
+//   D   stress tensor with the per-cell viscosity (4-cell average at the corners)
+//   E   viscous heating Q+ (:496-536), SubStep3's energy update (:956-1051), floor/ceiling
+// Reads Sigma, Phi, v_r, v_phi, e once and writes v_r, v_phi, e, Q+, Q- once (10 doubles per
+// cell); the c_s / H / nu / T grids of the step are not written: fcpt_post recomputes them from
+// the final state, as recalculate_derived_disk_quantities does.
+// COOL: the cooling terms of SubStep3 are compiled in (their opacity laws would otherwise cost the
+// common no-cooling case 70 registers: 134 -> 208 VGPRs)
+template <int AV, bool COOL> // AV 0: none, 1: TW, 2: SN
+__global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs, int rows_per_chunk)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int chunk = wave / segs;
+    const int seg = wave - chunk * segs;
+    const int nr = P.nr, nphi = P.nphi;
+    const int k0 = chunk * rows_per_chunk;
+    if (k0 > nr)
+        return;
+    const int k1 = (k0 + rows_per_chunk < nr + 1) ? k0 + rows_per_chunk : nr + 1; // v_r has rows 0..nr
+    const int jraw = seg * MARCH_VALID - MARCH_LO + lane;
+    const int j = jraw < 0 ? jraw + nphi : (jraw >= nphi ? jraw - nphi : jraw);
+    const bool store_lane = lane >= MARCH_LO && lane < MARCH_LO + MARCH_VALID && jraw < nphi;
+    const double dt = P.clk->dt;
+    const double C2 = P.art_visc_factor * P.art_visc_factor;
+    const double gm1 = P.gamma - 1.0;
+    const double inv_sqrt_gamma = 1.0 / sqrt(P.gamma);
+    const bool dissipate = P.art_visc_dissipation != 0;
+    constexpr bool cooling = COOL;
+
+#define NEXT(x) lane_next(x) /* value of cell j+1 */
+#define PREV(x) lane_prev(x) /* value of cell j-1 */
+    auto crow = [nr](int r) { return r < 0 ? 0 : (r > nr - 1 ? nr - 1 : r); };   // cell rows
+    auto vrow = [nr](int r) { return r < 0 ? 0 : (r > nr ? nr : r); };           // v_r rows
+
+    // rolling state (suffix _1.._3 = rings m-1..m-3)
+    double S_m = 0, S_1 = 0, S_2 = 0, S_3 = 0, Sp_m = 0, Sp_1 = 0, Sp_2 = 0; // Sigma and Sigma(j-1)
+    double F_m = 0, F_1 = 0;                                               // potential
+    double Pr_m = 0, Pr_1 = 0;                                             // pressure
+    double e0_m = 0, e0_1 = 0;                                             // energy as loaded
+    double e2_1 = 0, e2_2 = 0;                                             // after S3 + dissipation + floor
+    double nu_1 = 0, nu_2 = 0, nup_1 = 0, nup_2 = 0, H_1 = 0, H_2 = 0;     // viscosity (and at j-1), scale height
+    double va0_m = 0, va0_1 = 0, va0n_m = 0, va0n_1 = 0;                   // v_phi (input) and (j+1)
+    double vr1_m = 0, vr1_1 = 0, va1_m = 0, va1_1 = 0;                      // after source terms
+    double qr_1 = 0, qr_2 = 0, qp_1 = 0, qp_2 = 0;                          // Q_rr/Q_pp (TW) or q_r/q_phi (SN)
+    double vr2_1 = 0, vr2_2 = 0, va2_1 = 0, va2_2 = 0;                      // after artificial viscosity
+    double trr_2 = 0, trr_3 = 0, tpp_2 = 0, tpp_3 = 0, trp_1 = 0, trp_2 = 0;
+
+    // ring k0-3 is the "previous" ring of the first iteration
+    {
+        const int r = crow(k0 - 3);
+        S_m = P.sigma[IDX(r, j)];
+        F_m = P.potential[IDX(r, j)];
+        va0_m = P.vazi[IDX(r, j)];
+        e0_m = P.energy[IDX(r, j)];
+        Pr_m = gm1 * e0_m;
+        Sp_m = PREV(S_m);
+        va0n_m = NEXT(va0_m);
+    }
+    // software prefetch of the next input ring
+    int rn = k0 - 2;
+    double pS = P.sigma[IDX(crow(rn), j)], pF = P.potential[IDX(crow(rn), j)], pE = P.energy[IDX(crow(rn), j)];
+    double pVa = P.vazi[IDX(crow(rn), j)], pVr = P.vrad[IDX(vrow(rn), j)];
+
+    for (int m = k0 - 2; m <= k1 + 1; ++m) {
+        const SrcRow R = crow_load(P.src_tab, m + 2); // every per-ring factor of this iteration, one batch
+        // ---- shift the window, take the prefetched ring m, prefetch ring m+1 ------------
+        S_3 = S_2; S_2 = S_1; S_1 = S_m; Sp_2 = Sp_1; Sp_1 = Sp_m;
+        F_1 = F_m; Pr_1 = Pr_m; e0_1 = e0_m;
+        va0_1 = va0_m; va0n_1 = va0n_m;
+        vr1_1 = vr1_m; va1_1 = va1_m;
+        e2_2 = e2_1; nu_2 = nu_1; nup_2 = nup_1; H_2 = H_1;
+        S_m = pS; F_m = pF; va0_m = pVa; e0_m = pE;
+        const double vr0_m = pVr;
+        {
+            const int r = m + 1;
+            pS = P.sigma[IDX(crow(r), j)];
+            pF = P.potential[IDX(crow(r), j)];
+            pE = P.energy[IDX(crow(r), j)];
+            pVa = P.vazi[IDX(crow(r), j)];
+            pVr = P.vrad[IDX(vrow(r), j)];
+        }
+        Pr_m = gm1 * e0_m;
+        Sp_m = PREV(S_m);
+        va0n_m = NEXT(va0_m);
+        const double Fp_m = PREV(F_m);
+        const double Prp_m = PREV(Pr_m);
+
+        // ---- A: source terms on ring m ---------------------------------------------------
+        {
+            const int r = m;
+            vr1_m = vr0_m;
+            if (r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr) {
+                double gradp = 2.0 * fast_rcp(S_m + S_1);
+                gradp *= (Pr_m - Pr_1);
+                gradp *= R.idr_m;
+                const double gradphi = (F_m - F_1) * R.idr_m;
+                const double vsum = va0_m + va0n_m + va0_1 + va0n_1;
+                const double vt = 0.25 * vsum + R.rinf_om_m;
+                const double vt2 = vt * vt;
+                vr1_m = vr0_m + dt * (-gradp - gradphi + vt2 * R.inv_rinf_m);
+            }
+            va1_m = va0_m;
+            if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
+                const double invdxtheta = R.inv_dxt_m; // 2 / (dphi (Rsup + Rinf))
+                const double gradp = 2.0 * fast_rcp(S_m + Sp_m) * (Pr_m - Prp_m) * invdxtheta;
+                const double gradphi = (F_m - Fp_m) * invdxtheta;
+                va1_m = va0_m + dt * (-gradp - gradphi);
+            }
+        }
+        // ---- S3 + B: compression heating, artificial pressure and its dissipation, ring m-1 --
+        qr_2 = qr_1; qp_2 = qp_1;
+        {
+            const int r = m - 1;
+            const double va1n_1 = NEXT(va1_1);
+            double e = e0_1;
+            if (r < nr - 1) { // compression_heating, rows [0, Nr-1)
+                const double DIV_V = (vr1_m * R.rinf_b1 - vr1_1 * R.rinf_b0) * R.inv_drsuprb_b +
+                                     (va1n_1 - va1_1) * P.invdphi * R.inv_rmed_b;
+                e = e * exp(-gm1 * dt * DIV_V);
+            }
+            if (AV == 1) {
+                const double eps_rr = (vr1_m - vr1_1) * R.inv_drsup_b;
+                const double eps_pp = R.inv_rmed_b * ((va1n_1 - va1_1) * P.invdphi + 0.5 * (vr1_m + vr1_1));
+                const double div_V = dmin(eps_rr + eps_pp, 0.0);
+                const double l_sq = R.lsq_b;
+                qr_1 = l_sq * S_1 * -div_V * (eps_rr - 1.0 / 3.0 * div_V);
+                qp_1 = l_sq * S_1 * -div_V * (eps_pp - 1.0 / 3.0 * div_V);
+                if (dissipate && r > P.zero_no_ghost && r < P.max_no_ghost) {
+                    const double Qplus = -l_sq * div_V * S_1 * 1.0 / 3.0 *
+                                         (eps_rr * eps_rr + eps_pp * eps_pp + (eps_rr - eps_pp) * (eps_rr - eps_pp));
+                    e += Qplus * dt;
+                }
+            } else if (AV == 2) {
+                const double dv_r = vr1_m - vr1_1;
+                qr_1 = dv_r < 0.0 ? C2 * S_1 * (dv_r * dv_r) : 0.0;
+                const double dv_phi = va1n_1 - va1_1;
+                qp_1 = dv_phi < 0.0 ? C2 * S_1 * (dv_phi * dv_phi) : 0.0;
+                if (dissipate && r >= P.zero_no_ghost && r < P.max_no_ghost)
+                    e = e - dt * qr_1 * dv_r * R.inv_drsup_b - dt * qp_1 * dv_phi * R.inv_dxtheta_b;
+            }
+            if (dissipate) // update_with_artificial_viscosity ends with the temperature floor/ceiling
+                e = clamp_energy_fast(P, e, S_1);
+            e2_1 = e;
+            // V0: recalculate_viscosity on ring m-1
+            const double cs = sqrt(P.gamma * gm1 * e * fast_rcp(S_1));
+            H_1 = cs * inv_sqrt_gamma * R.inv_omk_b;
+            nu_1 = P.alpha_viscosity ? P.alpha * H_1 * cs : P.nu_const;
+            nup_1 = PREV(nu_1);
+        }
+        // ---- C: artificial-viscosity update of ring m-1 -----------------------------------
+        vr2_2 = vr2_1; va2_2 = va2_1;
+        {
+            const int r = m - 1;
+            vr2_1 = vr1_1;
+            va2_1 = va1_1;
+            const bool upd_vr = r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr;
+            if (AV == 1) {
+                const double qpp_p = PREV(qp_1);
+                if (r >= 1 && r < nr - 1) {
+                    const double sigma_phi_avg = 0.5 * (S_1 + Sp_1);
+                    va2_1 = va1_1 + 2.0 * dt * (R.inv_rsum_c * fast_rcp(sigma_phi_avg)) * (qp_1 - qpp_p) * P.invdphi;
+                }
+                if (upd_vr) {
+                    const double sigma_r_avg = 0.5 * (S_1 + S_2);
+                    const double rm = R.rmed_c, rmm = R.rmed_cm1;
+                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt * fast_rcp(sigma_r_avg) * 2.0 * R.inv_drmed2_c *
+                                        ((qr_1 * rm - qr_2 * rmm) - 0.5 * (qp_1 + qp_2) * (rm - rmm));
+                }
+            } else if (AV == 2) {
+                const double qphi_p = PREV(qp_1);
+                if (upd_vr)
+                    vr2_1 = vr1_1 - dt * 2.0 * fast_rcp(S_1 + S_2) * (qr_1 - qr_2) * R.idr_c;
+                if (r >= P.zero_no_ghost && r < P.max_no_ghost)
+                    va2_1 = va1_1 - dt * 2.0 * fast_rcp(S_1 + Sp_1) * (qp_1 - qphi_p) * R.inv_dxtheta_b;
+            }
+        }
+        // ---- D: stress tensor: diagonal on ring m-2, r-phi on ring m-1 --------------------
+        trr_3 = trr_2; tpp_3 = tpp_2; trp_2 = trp_1;
+        double divv_2;
+        {
+            const double va2n_2 = NEXT(va2_2);
+            const double dva = va2n_2 - va2_2;
+            divv_2 = (vr2_1 * R.rinf_d1 - vr2_2 * R.rinf_d0) * R.inv_drsuprb_d + dva * P.invdphi * R.inv_rmed_d;
+            const double drr = (vr2_1 - vr2_2) * R.inv_drsup_d;
+            trr_2 = 2.0 * nu_2 * S_2 * (drr - 1.0 / 3.0 * divv_2);
+            const double dpp = dva * P.invdphi * R.inv_rmed_d + 0.5 * (vr2_1 + vr2_2) * R.inv_rmed_d;
+            tpp_2 = 2.0 * nu_2 * S_2 * (dpp - 1.0 / 3.0 * divv_2);
+        }
+        {
+            const int r = m - 1;
+            const double vr2p_1 = PREV(vr2_1);
+            trp_1 = 0.0;
+            if (r >= 1 && r <= nr - 1) {
+                const double dvazirdr = (va2_1 * R.inv_rmed_r - va2_2 * R.inv_rmed_rm1) * R.idr_r;
+                const double dvrdphi = (vr2_1 - vr2p_1) * P.invdphi;
+                const double drp = R.rinf_r * dvazirdr + dvrdphi * R.inv_rinf_r;
+                const double nu = 0.25 * (nu_1 + nu_2 + nup_1 + nup_2);
+                const double sigma = 0.25 * (S_1 + S_2 + Sp_1 + Sp_2);
+                trp_1 = nu * sigma * drp;
+            }
+        }
+        // ---- E: viscous update, viscous heating and SubStep3 of ring k = m-2, store -------
+        {
+            const int k = m - 2;
+            const double tpp_p = PREV(tpp_2);
+            const double trp_n = NEXT(trp_2);
+            const double trp_1n = NEXT(trp_1);
+            if (k >= k0 && k < k1) {
+                double vr3 = vr2_2, va3 = va2_2;
+                const bool row_va = k >= 1 && k < nr - 1;
+                if (row_va) {
+                    const double sigma_avg = 0.5 * (S_2 + Sp_2);
+                    va3 = va2_2 + dt * R.inv_rmed_k * fast_rcp(sigma_avg) *
+                                      (R.two_inv_dra2_k * (R.ra1sq_k * trp_1 - R.ra0sq_k * trp_2) +
+                                       (tpp_2 - tpp_p) * P.invdphi);
+                }
+                if (k >= P.one_no_ghost_vr && k < P.maxmo_no_ghost_vr) {
+                    const double sigma_avg = 0.5 * (S_2 + S_3);
+                    vr3 = vr2_2 + dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
+                                      ((R.rmed_k * trr_2 - R.rmed_km1 * trr_3) * R.idr_k +
+                                       (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
+                }
+                double qplus = 0.0, qminus = 0.0, e = e2_2;
+                if (k < nr) {
+                    if (P.heating_viscous && row_va && nu_2 != 0.0) { // viscous_heating
+                        const double tau_r_phi = 0.25 * (trp_2 + trp_1 + trp_n + trp_1n);
+                        double q = fast_rcp(2.0 * nu_2 * S_2) * (trr_2 * trr_2 + 2 * (tau_r_phi * tau_r_phi) + tpp_2 * tpp_2);
+                        q += (2.0 / 9.0) * nu_2 * S_2 * (divv_2 * divv_2);
+                        q *= P.heating_viscous_factor;
+                        qplus += q;
+                    }
+                    if (row_va) { // SubStep3, rows [1, Nr-1)
+                        const double bb = P.b_fac * fast_rcp(S_2), b2 = bb * bb; // substep3_alpha
+                        const double alpha = 1.0 + 2.0 * H_2 * 4.0 * P.sigma_sb / P.c_light * (b2 * b2) * (e * e * e);
+                        const double ralpha = fast_rcp(alpha);
+                        double tau_eff = 0.0;
+                        if (cooling) { // calculate_qminus
+                            const Cooling cool = cooling_terms(P, k, IDX(k, j), S_2, e, H_2);
+                            qminus = cool.qminus * ralpha;
+                            tau_eff = cool.tau_eff;
+                        }
+                        qplus = qplus * ralpha;
+                        double energy_new = e + dt * (qplus - qminus);
+                        const double SigmaFloor = 10.0 * P.sigma0_val * P.sigma_floor_rel;
+                        if (S_2 < SigmaFloor) {
+                            const double e4 = qplus * tau_eff / (2.0 * P.sigma_sb);
+                            energy_new = sqrt(sqrt(e4)) * (P.Rgas / P.mu * S_2 / (P.gamma - 1.0));
+                            qminus = qplus;
+                        }
+                        e = energy_new;
+                    }
+                    e = clamp_energy_fast(P, e, S_2); // SetTemperatureFloorCeilValues
+                }
+                if (store_lane) {
+                    P.vrad_b[IDX(k, j)] = vr3;
+                    if (k < nr) {
+                        P.vazi_b[IDX(k, j)] = va3;
+                        P.energy_b[IDX(k, j)] = e;
+                        P.qplus[IDX(k, j)] = qplus;
+                        P.qminus[IDX(k, j)] = qminus;
+                        // step_LeapFrog evaluates the mid-step potential with the scale height this kick's
+                        // recalculate_viscosity left behind (simulation.cpp:340-378), not with that of the
+                        // transported state: keep the grid for it
+                        if (P.leapfrog)
+                            P.scale_height[IDX(k, j)] = H_2;
+                    }
+                }
+            }
+        }
+    }
+#undef NEXT
+#undef PREV
+}

@@ -1,0 +1,380 @@
+// Part of fcpt_kernels.hip (one translation unit, namespace fcpt): k_transport_fused: the whole Transport() in one marching kernel.
+// Not a stand-alone header: included once, in the order given there.
+
+// ===========================================================================
+// The whole Transport() (TransportEuler.cpp:112-136) in ONE pass over memory.
+//
+// A wavefront owns 64*C consecutive phi columns in PRE-shift coordinates and marches outward
+// ring by ring.  Per step it loads one ring of Sigma, v_r, v_phi(, e) (the only HBM reads), and
+//   R  radial sweep: specific momenta w(m), limited half slopes of ring m-1, the upwind fluxes
+//      through interface m-1 (each evaluated once, shared mass flux), update of ring m-2
+//      (compute_momenta_from_velocities + OneWindRad, :138-167,471-493,545-620) -- all column-local,
+//      a rolling register window of three rings;
+//   T  both azimuthal passes on ring m-2 (theta_pass, as k_transport_theta_march) with phi
+//      neighbours by DPP lane shifts;
+//   V  velocities from momenta, floors, wave damping (:498-535,121-131) and the store of the new
+//      state at the POST-shift address (column + Nshift[i], AdvectSHIFT :238-268 is free).
+// v_r(i) couples rings i-1 and i at one post-shift column, i.e. at lanes that differ by
+// Nshift[i] - Nshift[i-1].  The FARGO shear limit of the CFL condition (cfl.cpp:207-220) keeps
+// that difference in {-1, 0, 1} for every admissible dt, so one lane shift of the previous ring
+// is enough; k_ring_mean raises P.shift_jump otherwise and the unfused kernels run instead.
+// Nothing intermediate reaches memory: 3 (4) grids read + 3 (4) written instead of 8 + 9
+// (10 + 11) doubles per cell for k_transport_radial + k_transport_theta_march.
+// Validity in cells of a 64*C segment: right 1 (L+ needs v_phi(j+1)), 4 at either end for the
+// two passes, left 1 for L+(j-1), 1 at either end for the v_r lane shift.
+#define TF_ROWS 24
+template <int C> struct TfHalo {
+    static constexpr int lo = C == 2 ? 6 : 5; // even for C = 2: a lane's two cells are final together
+    static constexpr int hi = 6;
+};
+
+// wave damping with the ring's precomputed exp(-dt f / tau) (k_ring_mean): types as damp_value
+__device__ __forceinline__ double damp_apply(double X, int type, double ef, const double *ref, int cell, double zero_target)
+{
+    if (type == 0)
+        return X;
+    const double X0 = type == 1 ? ref[cell] : zero_target;
+    return (X - X0) * ef + X0;
+}
+
+template <int C, bool ADI, bool DAMP, int LIM>
+__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int has_fallback)
+{
+    // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
+    constexpr int LO = TfHalo<C>::lo, HI = TfHalo<C>::hi;
+    constexpr int NQ = ADI ? 6 : 5; // s, rmp, rmm, lp, lm(, e)
+    constexpr int lim = LIM;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int chunk = wave / tiles;
+    const int r0 = chunk * rows;
+    const int nr = P.nr, nphi = P.nphi;
+    if (r0 >= nr)
+        return;
+    const int r1 = r0 + rows < nr ? r0 + rows : nr;
+    if (wave == 0 && lane == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
+        W.clk->time += P.clk->dt;
+        W.clk->n_hydro_iter += 1;
+    }
+    { // the lane shift of the previous ring covers |Nshift[i] - Nshift[i-1]| <= 1 only
+        bool jump = false;
+        int prev = P.nshift_c[r0 > 0 ? r0 - 1 : 0] % nphi;
+        for (int i = r0; i < r1; ++i) {
+            const int cur = P.nshift_c[i] % nphi;
+            int dd = cur - prev;
+            dd = dd < 0 ? -dd : dd;
+            dd = dd > nphi / 2 ? nphi - dd : dd;
+            jump = jump || dd > 1;
+            prev = cur;
+        }
+        if (jump) {
+            if (lane == 0) {
+                *P.shift_jump = 1;
+                if (!has_fallback) // nothing behind this kernel will redo the step: report it
+                    W.clk->shear_error = 1;
+            }
+            return;
+        }
+    }
+    const int tile = wave - chunk * tiles;
+    const int stride = 64 * C - (LO + HI);
+    const int a = tile * stride - LO; // first pre-shift column of the segment
+    const double dt = P.clk->dt;
+    auto wrap = [nphi](int j) { return j < 0 ? j + nphi : (j >= nphi ? j - nphi : j); };
+
+    int jin[C];
+    bool valid[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int pos = lane * C + c;
+        jin[c] = wrap(a + pos);
+        valid[c] = pos >= LO && pos < 64 * C - HI && a + pos < nphi;
+    }
+    const bool pair_in = C == 2 && __builtin_amdgcn_ballot_w64(jin[C - 1] != jin[0] + 1) == 0;
+    const bool pair_valid = C == 2 && __builtin_amdgcn_ballot_w64(valid[0] != valid[C - 1]) == 0;
+
+    // rolling window: index 0 = ring m (newest), 1 = m-1, 2 = m-2
+    double w[3][NQ][C];  // specific quantities: Sigma, v_r(ring+1), v_r(ring), (v_phi(j+1) + r Omega) r, (v_phi + r Omega) r(, e / Sigma)
+    double er[3][C];     // the energy itself
+    double vp[3][C];     // v_phi as loaded
+    double d1[NQ][C];    // (w(m-1) - w(m-2)) InvDiffRmed[m-1]
+    double hs1[NQ][C];   // limited half slope of ring m-2
+    double F1[NQ][C];    // flux through interface m-2
+    double rmp_prev[C], S_prev[C]; // transported rm+ and Sigma of the previous ring
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            w[0][q][c] = w[1][q][c] = w[2][q][c] = d1[q][c] = hs1[q][c] = F1[q][c] = 0.0;
+        er[0][c] = er[1][c] = er[2][c] = vp[0][c] = vp[1][c] = vp[2][c] = 0.0;
+        rmp_prev[c] = S_prev[c] = 0.0;
+    }
+    // raw loads of one ring: Sigma(k), v_phi(k)(, e(k)) and v_r(k+1); zeros outside the grid
+    struct RingRaw {
+        double sg[C], va[C], en[C], vr[C];
+    };
+    auto fetch = [&](int k, RingRaw &o) {
+        const bool in_k = k >= 0 && k < nr;
+        const bool in_v = k + 1 >= 0 && k + 1 <= nr;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            o.sg[c] = o.va[c] = o.en[c] = o.vr[c] = 0.0;
+        const size_t row = (size_t)(in_k ? k : 0) * nphi, rowv = (size_t)(in_v ? k + 1 : 0) * nphi;
+        if (pair_in) {
+            if (in_k) {
+                const D2 s2 = LD2(P.sigma + row + jin[0]), v2 = LD2(P.vazi + row + jin[0]);
+                o.sg[0] = s2.x, o.sg[C - 1] = s2.y, o.va[0] = v2.x, o.va[C - 1] = v2.y;
+                if (ADI) {
+                    const D2 e2 = LD2(P.energy + row + jin[0]);
+                    o.en[0] = e2.x, o.en[C - 1] = e2.y;
+                }
+            }
+            if (in_v) {
+                const D2 r2 = LD2(P.vrad + rowv + jin[0]);
+                o.vr[0] = r2.x, o.vr[C - 1] = r2.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (in_k) {
+                    o.sg[c] = P.sigma[row + jin[c]];
+                    o.va[c] = P.vazi[row + jin[c]];
+                    if (ADI)
+                        o.en[c] = P.energy[row + jin[c]];
+                }
+                if (in_v)
+                    o.vr[c] = P.vrad[rowv + jin[c]];
+            }
+        }
+    };
+    // ring k (raw) -> newest window slot; vr_k = v_r(k) from the previous ring's fetch
+    double vr_last[C];
+    auto convert = [&](int k, const RingRaw &o) {
+        const bool in_k = k >= 0 && k < nr;
+        const ThetaRow tk = crow_load(P.theta_tab, in_k ? k : 0);
+        const double r = tk.rmed, romega = tk.r_omega;
+        const double va_n = lane_next(o.va[0]); // v_phi of cell j+1 of the last cell of the lane
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double van = c == C - 1 ? va_n : o.va[c == C - 1 ? c : c + 1];
+            w[0][0][c] = o.sg[c];
+            w[0][1][c] = in_k ? o.vr[c] : 0.0;                        // rm+ / Sigma = v_r(k+1)   (:484-485)
+            w[0][2][c] = in_k ? vr_last[c] : 0.0;                     // rm- / Sigma = v_r(k)
+            w[0][3][c] = in_k ? (van + romega) * r : 0.0;             // L+ / Sigma = (v_phi(j+1) + r Omega) r
+            w[0][4][c] = in_k ? (o.va[c] + romega) * r : 0.0;         // L- / Sigma
+            if (ADI) {
+                w[0][NQ - 1][c] = in_k ? o.en[c] * fast_rcp(o.sg[c]) : 0.0;
+                er[0][c] = o.en[c];
+            }
+            vp[0][c] = o.va[c];
+            vr_last[c] = o.vr[c];
+        }
+    };
+    // Software pipeline of the memory traffic: ring m+1 is in flight while ring m-2 is computed;
+    // at the bottom of an iteration the arrived ring is converted, the loads of ring m+2 are
+    // issued, and only then the iteration's stores.  The one s_waitcnt vmcnt(0) per iteration then
+    // meets operations that are a whole compute phase old (vmcnt counts stores too; waiting right
+    // behind them costs a round trip per ring at 2-3 waves per SIMD).
+    RingRaw nxt;
+    fetch(r0 - 4, nxt);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        vr_last[c] = nxt.vr[c]; // v_r(r0-3)
+    fetch(r0 - 3, nxt);
+    convert(r0 - 3, nxt);
+    fetch(r0 - 2, nxt);
+    int ns_prev = 0;
+
+    for (int m = r0 - 3; m <= r1 + 1; ++m) {
+        // ---- per-ring scalars of this iteration in one batch ----------------------------------
+        const int k = m - 1, i = m - 2;
+        const bool do_i = i >= r0 - 1 && i >= 0 && i < r1;
+        const RadRow rk = crow_load(P.rad_tab, (k < -1 ? -1 : k) + 1);
+        const ThetaRow ti = crow_load(P.theta_tab, do_i ? i : 0);
+        const ShiftRow si = crow_load((const ShiftRow *)P.shift_tab, do_i ? i : 0);
+        DampRow di;
+        if (DAMP)
+            di = crow_load(W.damp_tab, do_i ? i : 0);
+        // ---- R: slopes of ring m-1, fluxes through interface k = m-1 --------------------------
+        double F0[NQ][C];
+        {
+            const double idr_m = rk.idr_up;          // 1 / (Rmed[m] - Rmed[m-1]) when both rings exist
+            const bool lim_ok = k > 0 && k < nr - 1; // boundary rings carry no slope (:360-372)
+            const bool open = k > 0 && k < nr;       // interface carries a flux
+            const double g = dt * rk.gphi;
+            bool up[C];
+            double dist[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double v = w[1][2][c]; // v_r(m-1)
+                up[c] = v > 0.0;
+                dist[c] = up[c] ? (rk.dr_lo - v * dt) : -(rk.dr_hi + v * dt);
+            }
+            double Fc[C];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double d0 = (w[0][q][c] - w[1][q][c]) * idr_m;
+                    const double hs0 = lim_ok ? half_limiter(lim, d0, d1[q][c]) : 0.0; // ring m-1
+                    const double st = (up[c] ? w[2][q][c] : w[1][q][c]) + dist[c] * (up[c] ? hs1[q][c] : hs0);
+                    if (q == 0) {
+                        Fc[c] = open ? g * st * w[1][2][c] : 0.0; // mass flux g rho* v
+                        F0[q][c] = Fc[c];
+                    } else {
+                        F0[q][c] = st * Fc[c];
+                    }
+                    d1[q][c] = d0;
+                    hs1[q][c] = hs0;
+                }
+            }
+        }
+        // ---- update of ring i = m-2, azimuthal passes, velocities -----------------------------
+        bool out_on = false, out_pair = false;
+        int out_g[C];
+        double o_vr[C], o_va[C], o_s[C], o_e[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            out_g[c] = 0, o_vr[c] = o_va[c] = o_s[c] = o_e[c] = 0.0;
+        if (do_i) {
+            const double invsurf = ti.invsurf;
+            double S[C], Q[4][C], E[C], V[C];
+            const double mean = si.mean;
+            const double vconst = si.vconst;
+            const double vadd = P.fast_transport ? 0.0 : vconst;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double s0 = w[2][0][c];
+                S[c] = s0 + (F1[0][c] - F0[0][c]) * invsurf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    Q[q][c] = s0 * w[2][q + 1][c] + (F1[q + 1][c] - F0[q + 1][c]) * invsurf;
+                E[c] = ADI ? er[2][c] + (F1[NQ - 1][c] - F0[NQ - 1][c]) * invsurf : 0.0;
+                V[c] = vadd + (vp[2][c] - mean);
+            }
+            const double dxtheta = ti.dxtheta;
+            const double invdx = ti.inv_dxtheta;
+            const double geo_dt = ti.dr_invsurf * dt;
+            theta_pass<C, ADI, false, 0>(lim, 0, 0, geo_dt, dxtheta, invdx, dt, V, 0.0, S, Q, E);
+            if (P.fast_transport) {
+                if (vconst * dt > 0.0)
+                    theta_pass<C, ADI, false, 1>(lim, 0, 0, geo_dt, dxtheta, invdx, dt, V, vconst, S, Q, E);
+                else
+                    theta_pass<C, ADI, false, 2>(lim, 0, 0, geo_dt, dxtheta, invdx, dt, V, vconst, S, Q, E);
+            }
+            int ns = si.nshift % nphi;
+            ns = ns < 0 ? ns + nphi : ns;
+            if (i >= r0) {
+                // the previous ring sits Nshift[i] - Nshift[i-1] lanes further right
+                int dsh = ns - ns_prev;
+                dsh = dsh > nphi / 2 ? dsh - nphi : (dsh < -(nphi / 2) ? dsh + nphi : dsh);
+                double rp[C], sp[C];
+                if (dsh == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        rp[c] = rmp_prev[c], sp[c] = S_prev[c];
+                } else if (dsh > 0) {
+                    const double rn = lane_next(rmp_prev[0]), sn = lane_next(S_prev[0]);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        rp[c] = c == C - 1 ? rn : rmp_prev[c == C - 1 ? c : c + 1];
+                        sp[c] = c == C - 1 ? sn : S_prev[c == C - 1 ? c : c + 1];
+                    }
+                } else {
+                    const double rl = lane_prev(rmp_prev[C - 1]), sl = lane_prev(S_prev[C - 1]);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        rp[c] = c == 0 ? rl : rmp_prev[c == 0 ? 0 : c - 1];
+                        sp[c] = c == 0 ? sl : S_prev[c == 0 ? 0 : c - 1];
+                    }
+                }
+                const double lp_l = lane_prev(Q[2][C - 1]); // L+ and Sigma of cell j-1
+                const double s_l = lane_prev(S[C - 1]);
+                const double invr = ti.invr, romega = ti.r_omega;
+                const int row = i * nphi;
+                int jout[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    int jo = jin[c] + ns;
+                    jout[c] = jo >= nphi ? jo - nphi : jo;
+                    const double lpm = c == 0 ? lp_l : Q[2][c == 0 ? 0 : c - 1];
+                    const double sm = c == 0 ? s_l : S[c == 0 ? 0 : c - 1];
+                    double vr = 0.0;
+                    if (i != 0)
+                        vr = (rp[c] + Q[1][c]) * fast_rcp(sp[c] + S[c]);
+                    double va = (lpm + Q[3][c]) * fast_rcp(sm + S[c]) * invr - romega;
+                    double sf = S[c] < P.sigma_floor_abs ? P.sigma_floor_abs : S[c];
+                    double e = ADI ? clamp_energy_fast(P, E[c], sf) : 0.0;
+                    const int g = row + jout[c];
+                    if (DAMP) {
+                        vr = damp_apply(vr, di.tvr, si.ev, W.vrad0, g, 0.0);
+                        va = damp_apply(va, di.tva, si.es, W.vazi0, g, 0.0);
+                        sf = damp_apply(sf, di.tsg, si.es, W.sigma0, g, W.sigma_floor_abs);
+                        if (ADI)
+                            e = damp_apply(e, di.ten, si.es, W.energy0, g, 0.0);
+                    }
+                    o_vr[c] = vr, o_va[c] = va, o_s[c] = sf, o_e[c] = e;
+                    out_g[c] = g;
+                }
+                out_on = true;
+                out_pair = pair_valid && __builtin_amdgcn_ballot_w64(jout[C - 1] != jout[0] + 1) == 0;
+            }
+            ns_prev = ns;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                rmp_prev[c] = Q[0][c];
+                S_prev[c] = S[c];
+            }
+        }
+        // ---- bottom: rotate, take ring m+1, start ring m+2, then this iteration's stores ------
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                w[2][q][c] = w[1][q][c];
+                w[1][q][c] = w[0][q][c];
+                F1[q][c] = F0[q][c];
+            }
+            er[2][c] = er[1][c], er[1][c] = er[0][c];
+            vp[2][c] = vp[1][c], vp[1][c] = vp[0][c];
+        }
+        if (m < r1 + 1) {
+            convert(m + 1, nxt);
+            if (m < r1)
+                fetch(m + 2, nxt);
+        }
+        if (out_on) {
+            if (out_pair) {
+                if (valid[0]) {
+                    ST2(W.vrad + out_g[0], (D2{o_vr[0], o_vr[C - 1]}));
+                    ST2(W.vazi + out_g[0], (D2{o_va[0], o_va[C - 1]}));
+                    ST2(W.sigma + out_g[0], (D2{o_s[0], o_s[C - 1]}));
+                    if (ADI)
+                        ST2(W.energy + out_g[0], (D2{o_e[0], o_e[C - 1]}));
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (valid[c]) {
+                        W.vrad[out_g[c]] = o_vr[c];
+                        W.vazi[out_g[c]] = o_va[c];
+                        W.sigma[out_g[c]] = o_s[c];
+                        if (ADI)
+                            W.energy[out_g[c]] = o_e[c];
+                    }
+            }
+            if (i == nr - 1) { // v_r row Nr is neither transported nor shifted: copied column by column
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (valid[c]) {
+                        double v = P.vrad[nr * nphi + jin[c]];
+                        if (DAMP) {
+                            const DampRow dn = crow_load(W.damp_tab, nr);
+                            v = damp_apply(v, dn.tvr, si.ev_top, W.vrad0, nr * nphi + jin[c], 0.0);
+                        }
+                        W.vrad[nr * nphi + jin[c]] = v;
+                    }
+            }
+        }
+    }
+}
