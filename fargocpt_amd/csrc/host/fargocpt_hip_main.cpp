@@ -463,6 +463,64 @@ int main(int argc, char **argv)
                 1, sp[d.radial_spacing]);
         fclose(f);
         remove((outdir + "snapshots/list.txt").c_str());
+        // units.yml (write_code_units_file, src/units.cpp:449-497) and info2D.yml (src/output.cpp:786-846):
+        // what the reference's Python loader (python_module/fargocpt/data.py) needs beside the grids
+        const double len = L0, mass = M0, tim = TIME0, temp = TEMP0;
+        const double energy = len * len * mass / (tim * tim), vel = len / tim;
+        struct U {
+            const char *name, *sym;
+            double v;
+        };
+        const U units[] = {
+            {"length", "cm", len},
+            {"mass", "g", mass},
+            {"time", "s", tim},
+            {"temperature", "K", temp},
+            {"energy", "erg", energy},
+            {"energy surface density", "erg cm^-2", mass / (tim * tim)},
+            {"density", "g cm^-3", mass / (len * len * len)},
+            {"mass surface density", "g cm^-2", mass / (len * len)},
+            {"opacity", "g^-1 cm^2", len * len / mass},
+            {"energy flux", "erg cm^-2 s^-1", energy / (len * len * tim)},
+            {"velocity", "cm s^-1", vel},
+            {"angular momentum", "cm^2 g s^-1", len * mass * vel},
+            {"kinematic viscosity", "cm^2 s^-1", len * len / tim},
+            {"dynamic viscosity", "P", mass / (len * tim)},
+            {"acceleration", "cm s^-2", len / (tim * tim)},
+            {"stress", "g s^-2", mass / (tim * tim)},
+            {"pressure", "dyn cm^-1", mass / (tim * tim)},
+            {"power", "erg/s", mass * len * len / (tim * tim * tim)},
+            {"potential", "erg/g", len * len / (tim * tim)},
+            {"torque", "erg", len * len * mass / (tim * tim)},
+            {"force", "dyn", mass * len / (tim * tim)},
+            {"mass accretion rate", "g s^-1", mass / tim},
+        };
+        f = fopen((outdir + "units.yml").c_str(), "w");
+        fprintf(f, "# code units file\n# version 0.2\n\n");
+        for (const U &u : units)
+            fprintf(f, "%s:\n  cgs symbol: %s\n  cgs value: %.17g\n  unit: %.17g %s\n\n", u.name, u.sym, u.v, u.v, u.sym);
+        fclose(f);
+        struct G {
+            const char *name, *sym;
+            double v;
+            bool vec;
+        };
+        const G grids[] = {{"Sigma", "g cm^-2", mass / (len * len), false},
+                           {"vrad", "cm s^-1", vel, true},
+                           {"vazi", "cm s^-1", vel, false},
+                           {"energy", "erg cm^-2", mass / (tim * tim), false},
+                           {"Temperature", "K", temp, false}};
+        f = fopen((outdir + "info2D.yml").c_str(), "w");
+        fprintf(f, "# 2D output variable descriptions\n# version 0.1\n\n");
+        for (const G &g : grids) {
+            if ((!strcmp(g.name, "energy") || !strcmp(g.name, "Temperature")) && d.eos != FCPT_EOS_IDEAL)
+                continue;
+            fprintf(f, "%s:\n  cgs symbols: %s\n  code_to_cgs_factor: %.17g\n  unit: %.17g %s\n  Nrad: %d\n  Nazi: %d\n",
+                    g.name, g.sym, g.v, g.v, g.sym, g.vec ? d.nr_global + 1 : d.nr_global, d.nphi);
+            fprintf(f, "  bigendian: 0\n  on_radial_interface: %s\n  on_azimuthal_interface: %s\n  filename: %s.dat\n\n",
+                    g.vec ? "true" : "false", !strcmp(g.name, "vazi") ? "true" : "false", g.name);
+        }
+        fclose(f);
     }
     auto write_snapshot = [&](unsigned nsnap, unsigned nmon) {
         fcpt_clock clk;

@@ -43,6 +43,17 @@ def test_shocktube_setup_files(tmp_path, setup, steps):
     assert open(out + "snapshots/list.txt").read().split() == ["0", "1"]
     misc = _misc(out + "snapshots/1/misc.bin")
     assert misc["snapshot"] == 1 and misc["n_iter"] == steps and abs(misc["time"] - 0.228) < 1e-12
+    # units.yml / info2D.yml as the reference's Python loader reads them (python_module/fargocpt/data.py:55-61,
+    # 680-700): every grid is found through its info2D entry
+    import yaml
+    units = yaml.safe_load(open(out + "units.yml"))
+    assert units["length"]["unit"].split()[1] == "cm" and abs(float(units["length"]["unit"].split()[0]) / 1.495978707e13 - 1) < 1e-12
+    info = yaml.safe_load(open(out + "info2D.yml"))
+    assert {"Sigma", "vrad", "vazi", "energy", "Temperature"} <= set(info)
+    for name, meta in info.items():
+        data = np.fromfile(out + "snapshots/1/" + meta["filename"])
+        assert data.size == meta["Nrad"] * meta["Nazi"], name
+        assert meta["on_radial_interface"] == (name == "vrad")
     # test/shockTube/check_results.py:93-127
     an = np.loadtxt(os.path.join(GOLDEN, "shocktube_analytic_shock.dat"), skiprows=2)
     r12 = np.loadtxt(out + "used_rad.dat")
