@@ -198,7 +198,11 @@ def main():
                          # busy fraction of the FP64 vector ALUs in this kernel (PMC, profiles/pmc_latest.json):
                          # k_transport_fused moves 48 B per cell instead of the model's 216 B and is bound by
                          # the vector pipeline, not by HBM
-                         "valu_busy": valu_busy},
+                         "valu_busy": valu_busy,
+                         "note": ("k_transport_fused does passes B+C+D of SURVEY.md 8(d)'s model (27|33 doubles per cell) "
+                                  "with 6|8 doubles of traffic; it is bound by the FP64 vector ALUs (valu_busy), not by HBM: "
+                                  "frac is its HBM fraction, step_frac the whole step against the 256|320 B model")
+                         if dominant == "k_transport_fused" else None},
             "kernel_ms_per_step": {k: v[0] / cal for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]},
         }
         if world == 1 and not args.no_cpu_baseline:
