@@ -234,6 +234,12 @@ class Context:
     def init_physics(self):
         self._call("init_physics")
 
+    def set_body_irradiation(self, temperature, radius, rampup_time=None):
+        t = np.ascontiguousarray(temperature, dtype=np.float64)
+        r = np.ascontiguousarray(radius, dtype=np.float64)
+        u = np.ascontiguousarray(rampup_time, dtype=np.float64) if rampup_time is not None else None
+        self._call("set_body_irradiation", _i32(len(t)), _as_dp(t), _as_dp(r), _as_dp(u))
+
     def disk_on_body_accel(self, x, y, r_object, smoothing_fixed=-1.0, cubic_smoothing_radius=0.0):
         """ComputeDiskOnPlanetAccel without the all-reduce: [inner a_x, inner a_y, outer a_x, outer a_y]."""
         out = (C.c_double * 4)()

@@ -949,6 +949,28 @@ int fcpt_set_bodies_midstep(fcpt_ctx *c, int32_t n, const double *x, const doubl
 }
 
 // init_euler (SourceEuler.cpp:251-285) + the tail of init_physics (init.cpp:337-341)
+int fcpt_set_body_irradiation(fcpt_ctx *c, int32_t n, const double *temperature, const double *radius,
+                              const double *rampup_time)
+{
+    if (!c || n < 0 || n > FCPT_MAX_BODIES || (n > 0 && (!temperature || !radius))) {
+        set_error("bad argument to fcpt_set_body_irradiation");
+        return FCPT_EINVAL;
+    }
+    if (!c->P.adiabatic) {
+        set_error("irradiation needs EquationOfState: ideal");
+        return FCPT_EINVAL;
+    }
+    c->P.heating_star = 0;
+    for (int k = 0; k < FCPT_MAX_BODIES; ++k) {
+        c->P.btemp[k] = k < n ? temperature[k] : 0.0;
+        c->P.bradius[k] = k < n ? radius[k] : 0.0;
+        c->P.bramp[k] = (k < n && rampup_time) ? rampup_time[k] : 0.0;
+        if (c->P.btemp[k] > 0.0)
+            c->P.heating_star = 1; // planetary_system.cpp:137-146
+    }
+    return FCPT_OK;
+}
+
 int fcpt_disk_on_body_accel(fcpt_ctx *c, double x, double y, double r_object, double smoothing_fixed,
                             double cubic_smoothing_radius, double out[4])
 {
@@ -988,7 +1010,7 @@ int fcpt_init_physics(fcpt_ctx *c)
     const size_t ns = (size_t)P.nr * P.nphi * sizeof(double);
     HIPCHK(hipMemsetAsync(P.qplus, 0, ns, st));
     HIPCHK(hipMemsetAsync(P.qminus, 0, ns, st));
-    if (P.adiabatic && (P.cooling_surface || P.cooling_beta)) {
+    if (P.adiabatic && (P.cooling_surface || P.cooling_beta || P.heating_star)) {
         // ... but Q- does not vanish: calculate_qminus + the 1/alpha of compute_heating_cooling_for_CFL
         Dev I = P;
         I.cooling_at_init = 1;

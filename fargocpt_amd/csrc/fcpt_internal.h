@@ -180,6 +180,8 @@ struct Dev {
     double tmin, tmax, sigma_floor_abs, sigma_floor_rel, sigma0_val;
     // cooling terms of SubStep3 (calculate_qminus)
     int cooling_surface, opacity, cooling_beta, cooling_beta_reference, cooling_at_init;
+    int heating_star;        // some body irradiates (parameters::heating_star_enabled)
+    double btemp[FCPT_MAX_BODIES], bradius[FCPT_MAX_BODIES], bramp[FCPT_MAX_BODIES];
     int kick_time_shift; // 1: second leapfrog kick -- its SubStep3 runs at clk.time - clk.dt (midstep_time)
     double cooling_radiative_factor, kappa_const, kappa_factor, tau_factor, tau_min, density_factor;
     double cooling_beta_value, cooling_beta_ramp_up, temperature_cgs, density_cgs, opacity_cgs;

@@ -248,8 +248,18 @@ void config_to_desc(const Config &c, fcpt_desc &d)
         }
         d.cooling_radiative_factor = num(c, "CoolingRadiativeFactor", 1.0);
         const std::string op = lower(c.str("Opacity", "Lin"));
-        d.opacity = op == "lin" ? FCPT_OPACITY_LIN : op == "bell" ? FCPT_OPACITY_BELL : op == "const" ? FCPT_OPACITY_CONST
-                                                                                                       : FCPT_OPACITY_SIMPLE;
+        if (op == "lin") { // read_opacity_config, src/parameters.cpp:424-439
+            d.opacity = FCPT_OPACITY_LIN;
+        } else if (op == "bell") {
+            d.opacity = FCPT_OPACITY_BELL;
+        } else if (op == "constant") {
+            d.opacity = FCPT_OPACITY_CONST;
+        } else if (op == "simple") {
+            d.opacity = FCPT_OPACITY_SIMPLE;
+        } else {
+            fprintf(stderr, "fargocpt_hip: Invalid choice for opacity type: %s\n", op.c_str());
+            exit(2);
+        }
         d.kappa_const = num(c, "KappaConst", 1.0);
         d.kappa_factor = num(c, "KappaFactor", 1.0);
         d.tau_factor = num(c, "TauFactor", 0.5);
@@ -446,6 +456,20 @@ int main(int argc, char **argv)
         CHECK(fcpt_set_bodies(ctx, n, x, y, m, rsm, 0.0, 0.0));
     };
     set_bodies(0.0);
+    { // irradiating bodies: 'temperature', 'radius', 'irradiation ramp-up time' (planetary_system.cpp:160-250)
+        double temp[FCPT_MAX_BODIES] = {0}, rad[FCPT_MAX_BODIES] = {0}, ramp[FCPT_MAX_BODIES] = {0};
+        bool any = false;
+        const int n = (int)std::min<size_t>(cfg.nbody.size(), FCPT_MAX_BODIES);
+        for (int k = 0; k < n; ++k) {
+            const auto &b = cfg.nbody[k];
+            temp[k] = b.count("temperature") ? number(b.at("temperature"), K_TEMP) : 0.0;
+            rad[k] = b.count("radius") ? number(b.at("radius"), K_LEN) : 0.0;
+            ramp[k] = b.count("irradiation ramp-up time") ? number(b.at("irradiation ramp-up time"), K_NONE) : 0.0;
+            any = any || temp[k] > 0.0;
+        }
+        if (any)
+            CHECK(fcpt_set_body_irradiation(ctx, n, temp, rad, ramp));
+    }
     CHECK(fcpt_init_physics(ctx));
 
     // ---- output files -------------------------------------------------------------------------

@@ -128,7 +128,7 @@ int launch_source_march(const Dev &P, hipStream_t st)
         const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
         const int chunks = (P.nr + 1 + rows - 1) / rows;
         const dim3 grid((segs * chunks + 3) / 4), block(256);
-        const bool cool = P.cooling_surface != 0 || P.cooling_beta != 0;
+        const bool cool = P.cooling_surface != 0 || P.cooling_beta != 0 || P.heating_star != 0;
 #define ADIK(AV_)                                                                                 \
     if (cool)                                                                                     \
         KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, true>), grid, block, P, segs, rows);  \

@@ -407,22 +407,24 @@ __device__ __forceinline__ double tau_eff_of(const Dev &P, double sigma, double 
     const double tau = P.tau_factor * (1.0 / P.density_factor) * kappa * sigma;
     if (P.opacity == FCPT_OPACITY_SIMPLE)
         return 3.0 / 8.0 * tau; // D'Angelo et al. 2003 eq. (28)
+    if (P.heating_star) // irradiated disk, D'Angelo & Marzari 2012
+        return 3.0 / 8.0 * tau + 0.5 + 1.0 / (4.0 * tau + P.tau_min);
     return 3.0 / 8.0 * tau + sqrt(3.0) / 4.0 + 1.0 / (4.0 * tau + P.tau_min);
 }
 // calculate_qminus (SourceEuler.cpp:931-950) at one cell of rows [1, Nr-1): beta cooling
 // (thermal_relaxation :632-786, without the opacity-based Ziampras variants) and thermal surface
 // cooling (:790-820).  tau_eff is returned for SubStep3's low-density branch (0 without surface cooling).
 struct Cooling {
-    double qminus, tau_eff;
+    double qminus, tau_eff, qplus_star; // qplus_star: irradiation by the bodies (SourceEuler.cpp:538-612)
 };
-__device__ __forceinline__ Cooling cooling_terms(const Dev &P, int i, int cell, double sigma, double energy, double H)
+__device__ __forceinline__ Cooling cooling_terms(const Dev &P, int i, int j, int cell, double sigma, double energy, double H)
 {
-    Cooling c = {0.0, 0.0};
+    Cooling c = {0.0, 0.0, 0.0};
+    const double tkick = P.clk->time - (P.kick_time_shift ? P.clk->dt : 0.0);
     if (P.cooling_beta && !(P.cooling_at_init && P.cooling_beta_reference == FCPT_BETAREF_REFERENCE)) {
         double beta_inv = 1 / P.cooling_beta_value;
         if (P.cooling_beta_ramp_up > 0.0) {
-            const double t = P.clk->time - (P.kick_time_shift ? P.clk->dt : 0.0);
-            const double x = 2 * t / P.cooling_beta_ramp_up;
+            const double x = 2 * tkick / P.cooling_beta_ramp_up;
             beta_inv = beta_inv * (1 - exp(-(x * x)));
         }
         double delta_E = energy;
@@ -437,11 +439,35 @@ __device__ __forceinline__ Cooling cooling_terms(const Dev &P, int i, int cell, 
         }
         c.qminus += delta_E * P.g_omk[i] * beta_inv;
     }
-    if (P.cooling_surface) {
+    if (P.cooling_surface || P.heating_star) {
         const double T = P.mu / P.Rgas * (P.gamma - 1.0) * energy / sigma; // compute_temperature
         c.tau_eff = tau_eff_of(P, sigma, H, T);
-        const double T2 = T * T, Tm2 = P.tmin * P.tmin;
-        c.qminus += P.cooling_radiative_factor * 2 * P.sigma_sb * (T2 * T2 - Tm2 * Tm2) / c.tau_eff;
+        if (P.cooling_surface) {
+            const double T2 = T * T, Tm2 = P.tmin * P.tmin;
+            c.qminus += P.cooling_radiative_factor * 2 * P.sigma_sb * (T2 * T2 - Tm2 * Tm2) / c.tau_eff;
+        }
+    }
+    if (P.heating_star) {
+        const double xc = P.Rmed[i] * P.cosphi[j], yc = P.Rmed[i] * P.sinphi[j];
+        const double HoverR = H * P.InvRmed[i]; // ASPECTRATIO
+        for (int k = 0; k < P.nbodies; ++k) {
+            if (!(P.btemp[k] > 0.0))
+                continue;
+            double ramping = 1.0;
+            if (tkick < P.bramp[k]) {
+                const double cs = cos(tkick * M_PI / 2.0 / P.bramp[k]);
+                ramping = 1.0 - cs * cs;
+            }
+            const double x = P.bx[k], y = P.by[k];
+            const double R_star = P.bradius[k], T_star = P.btemp[k];
+            const double min_dist = (x * x + y * y > 1e-10) ? dmax(R_star, P.brsm[k]) : R_star;
+            const double distance = dmax(sqrt((x - xc) * (x - xc) + (y - yc) * (y - yc)), min_dist);
+            const double roverd = distance < R_star ? 1.0 : R_star / distance;
+            const double W_G = 0.4 * roverd + HoverR * (9.0 / 7.0 - 1.0); // Chiang & Goldreich (1997)
+            const double Ts2 = T_star * T_star;
+            const double T_irrad_pow4 = (1.0 - 0.5) * (Ts2 * Ts2) * (roverd * roverd) * W_G;
+            c.qplus_star += ramping * (2.0 * P.sigma_sb * T_irrad_pow4 / c.tau_eff);
+        }
     }
     return c;
 }
@@ -455,8 +481,8 @@ template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
     const double sigma = P.sigma[IDX(i, j)];
     const double energy = P.energy[IDX(i, j)];
     const double alpha = substep3_alpha(P, H, sigma, energy);
-    const Cooling cool = cooling_terms(P, i, IDX(i, j), sigma, energy, H);
-    const double Qplus = P.qplus[IDX(i, j)] / alpha;
+    const Cooling cool = cooling_terms(P, i, j, IDX(i, j), sigma, energy, H);
+    const double Qplus = (P.qplus[IDX(i, j)] + cool.qplus_star) / alpha;
     double Qminus = (P.qminus[IDX(i, j)] + cool.qminus) / alpha;
     if (update_energy) {
         double energy_new = energy + dt * (Qplus - Qminus);

@@ -463,9 +463,10 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
                         const double ralpha = fast_rcp(alpha);
                         double tau_eff = 0.0;
                         if (cooling) { // calculate_qminus
-                            const Cooling cool = cooling_terms(P, k, IDX(k, j), S_2, e, H_2);
+                            const Cooling cool = cooling_terms(P, k, j, IDX(k, j), S_2, e, H_2);
                             qminus = cool.qminus * ralpha;
                             tau_eff = cool.tau_eff;
+                            qplus += cool.qplus_star;
                         }
                         qplus = qplus * ralpha;
                         double energy_new = e + dt * (qplus - qminus);

@@ -11,7 +11,7 @@ import numpy as np
 from . import binding as B
 
 
-def make_context(lib: B.Library, d: B.Desc, fields=None, radii=None, bodies=None) -> B.Context:
+def make_context(lib: B.Library, d: B.Desc, fields=None, radii=None, bodies=None, irradiation=None) -> B.Context:
     """Create a slab context, upload initial fields (generated when not given)
     and run init_physics."""
     d = d.copy()
@@ -27,6 +27,8 @@ def make_context(lib: B.Library, d: B.Desc, fields=None, radii=None, bodies=None
     ctx.upload(B.F_ENERGY, energy)
     if bodies is not None:
         ctx.set_bodies(*bodies)
+    if irradiation is not None:  # (temperature[], radius[], rampup_time[] | None) per body
+        ctx.set_body_irradiation(*irradiation)
     ctx.init_physics()
     return ctx
 

@@ -174,6 +174,22 @@ def temperature_test_theory(d: B.Desc, radii_med, sigma_code):
     return (27.0 / 64.0 * tau_fac * kappa0 * d.constant_viscosity / d.sigma_sb) ** 0.5 * sigma_code * omega
 
 
+def irradiation_test(lib: B.Library, nr=200, nphi=2):
+    """test/irradiation/angelo.yml: a passive disk heated by the star (T = 10 000 K, R = 1 solRadius)
+    and cooled through kappa = const (D'Angelo & Marzari 2012): returns (desc, bodies, irradiation)."""
+    d = temperature_test(lib, nr, nphi)
+    d.rmax = 100.0
+    d.damping_time_radius_outer = d.rmax
+    d.sigma0, d.sigma_slope, d.sigma_floor = 10.0 / SIGMA_CGS, 1.0, 1e-7
+    d.flaring_index = 0.3
+    d.constant_viscosity = 5.0e14 / (_L0 * _L0 / _T0)
+    d.heating_viscous = 0
+    d.opacity, d.kappa_const = B.OPACITY_CONST, 2.0e-6
+    bodies = ([0.0], [0.0], [d.hydro_center_mass])
+    irradiation = ([10000.0 / TEMP0_K], [6.957e10 / _L0], None)
+    return d, bodies, irradiation
+
+
 def jupiter_bodies(d: B.Desc):
     """Star + Jupiter of examples/config.yml for fcpt_set_bodies: the planet sits at
     (1, 0) in the frame rotating with OmegaFrame = 1 (no indirect term, no feedback)."""

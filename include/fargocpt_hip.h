@@ -299,6 +299,13 @@ int fcpt_set_bodies(fcpt_ctx *ctx, int32_t n, const double *x, const double *y, 
 int fcpt_set_bodies_midstep(fcpt_ctx *ctx, int32_t n, const double *x, const double *y, const double *mass,
                             const double *cubic_smoothing_radius);
 
+/* Stellar irradiation of the disk in SubStep3 (irradiation_single, src/SourceEuler.cpp:538-612): body k
+ * of fcpt_set_bodies heats the gas if temperature[k] > 0 (code units), with its radius (code units)
+ * and the ramp-up time of the heating.  Any irradiating body also switches the effective optical
+ * depth to the irradiated form (kappa_eff, src/compute.cpp:64-77).  Ideal EOS only. */
+int fcpt_set_body_irradiation(fcpt_ctx *ctx, int32_t n, const double *temperature, const double *radius,
+                              const double *rampup_time);
+
 /* Specific force of this slab's gas on an object at (x, y): ComputeDiskOnPlanetAccel
  * (src/Force.cpp:23-122) without its MPI_Allreduce -- out = {a_x, a_y} summed over the cells
  * of the rings inside `r_object` (the object's distance to the origin) followed by {a_x, a_y}

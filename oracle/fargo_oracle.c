@@ -49,6 +49,8 @@ struct orc_ctx {
     double *sigma0, *vrad0, *vazi0, *energy0;
     double *qr, *qphi, *divv, *trr, *tpp, *trp /* vector */, *qplus, *qminus, *density_int;
     double *tau_eff; /* kappa_eff (compute.cpp:41-87); 0 without surface cooling */
+    double btemp[FCPT_MAX_BODIES], bradius[FCPT_MAX_BODIES], bramp[FCPT_MAX_BODIES]; /* irradiating bodies */
+    int heating_star; /* parameters::heating_star_enabled */
     /* transport scratch (TransportEuler.cpp:32-50) */
     double *rmp, *rmm, *lp, *lm, *vres, *vmean, *work, *qrstar /* vector */, *densstar /* vector */,
         *tempshift, *dq;
@@ -759,6 +761,24 @@ int orc_set_bodies(orc_ctx *c, int32_t n, const double *x, const double *y, cons
     c->indirect_x = ix;
     c->indirect_y = iy;
     c->has_mid = 0;
+    return FCPT_OK;
+}
+
+int orc_set_body_irradiation(orc_ctx *c, int32_t n, const double *temperature, const double *radius,
+                             const double *rampup_time)
+{
+    if (!c || n < 0 || n > FCPT_MAX_BODIES || (n > 0 && (!temperature || !radius)))
+        return FCPT_EINVAL;
+    if (c->d.eos != FCPT_EOS_IDEAL)
+        return FCPT_EINVAL;
+    c->heating_star = 0;
+    for (int k = 0; k < FCPT_MAX_BODIES; ++k) {
+        c->btemp[k] = k < n ? temperature[k] : 0.0;
+        c->bradius[k] = k < n ? radius[k] : 0.0;
+        c->bramp[k] = (k < n && rampup_time) ? rampup_time[k] : 0.0;
+        if (c->btemp[k] > 0.0)
+            c->heating_star = 1; /* planetary_system.cpp:137-146 */
+    }
     return FCPT_OK;
 }
 
@@ -1559,13 +1579,15 @@ static double opacity_of(const fcpt_desc *d, double density, double temperature)
     return d->kappa_factor * rv;
 }
 /* compute.cpp:17-35 midplane_density + :41-87 kappa_eff at one cell: returns tau_eff */
-static double tau_eff_of(const fcpt_desc *d, double sigma, double H, double temperature)
+static double tau_eff_of(const fcpt_desc *d, int heating_star, double sigma, double H, double temperature)
 {
     const double rho = sigma / (d->density_factor * H);
     const double kappa = opacity_of(d, rho, temperature);
     const double tau = d->tau_factor * (1.0 / d->density_factor) * kappa * sigma;
     if (d->opacity == FCPT_OPACITY_SIMPLE)
         return 3.0 / 8.0 * tau; /* D'Angelo et al. 2003 eq. (28) */
+    if (heating_star) /* irradiated disk, D'Angelo & Marzari 2012 */
+        return 3.0 / 8.0 * tau + 0.5 + 1.0 / (4.0 * tau + d->tau_min);
     return 3.0 / 8.0 * tau + sqrt(3.0) / 4.0 + 1.0 / (4.0 * tau + d->tau_min);
 }
 /* SourceEuler.cpp:632-786 thermal_relaxation (beta cooling; the opacity-based Ziampras variants are
@@ -1604,17 +1626,23 @@ static void thermal_relaxation(orc_ctx *c, double current_time)
         }
 }
 /* SourceEuler.cpp:790-820 thermal_cooling (SurfaceCooling: thermal) */
-static void thermal_cooling(orc_ctx *c)
+static void kappa_eff(orc_ctx *c)
 {
-    const int Nr = c->nr - 1, Nphi = c->nphi;
+    const int Nphi = c->nphi;
     const fcpt_desc *d = &c->d;
     /* midplane_density recomputes the scale height from the current sound speed (compute.cpp:19) */
     compute_scale_height(c);
 #pragma omp parallel for if (c->big)
     for (int nr = 0; nr < c->nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz)
-            c->tau_eff[IDX(c, nr, naz)] = tau_eff_of(d, c->sigma[IDX(c, nr, naz)], c->scale_height[IDX(c, nr, naz)],
-                                                     c->temperature[IDX(c, nr, naz)]);
+            c->tau_eff[IDX(c, nr, naz)] = tau_eff_of(d, c->heating_star, c->sigma[IDX(c, nr, naz)],
+                                                     c->scale_height[IDX(c, nr, naz)], c->temperature[IDX(c, nr, naz)]);
+}
+static void thermal_cooling(orc_ctx *c)
+{
+    const int Nr = c->nr - 1, Nphi = c->nphi;
+    const fcpt_desc *d = &c->d;
+    kappa_eff(c);
 #pragma omp parallel for if (c->big)
     for (int nr = 1; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
@@ -1656,6 +1684,44 @@ static void calculate_qplus(orc_ctx *c)
             }
         }
 }
+/* SourceEuler.cpp:538-612 irradiation_single / irradiation: heating by the bodies that carry a temperature */
+static void irradiation(orc_ctx *c, double current_time)
+{
+    const int Nrad = c->nr - 1, Nphi = c->nphi;
+    const fcpt_desc *d = &c->d;
+    for (int k = 0; k < c->nbodies; ++k) {
+        if (!(c->btemp[k] > 0.0))
+            continue;
+        const double rampup_time = c->bramp[k];
+        double ramping = 1.0;
+        if (current_time < rampup_time) {
+            const double cs = cos(current_time * M_PI / 2.0 / rampup_time);
+            ramping = 1.0 - cs * cs;
+        }
+        const double x = c->bx[k], y = c->by[k];
+        const double R_star = c->bradius[k], T_star = c->btemp[k];
+        /* l1 * cubic smoothing factor is the cubic smoothing radius handed to fcpt_set_bodies */
+        const double min_dist = (x * x + y * y > 1e-10) ? fmax(R_star, c->brsm[k]) : R_star;
+        const double Ts2 = T_star * T_star;
+#pragma omp parallel for if (c->big)
+        for (int nrad = 1; nrad < Nrad; ++nrad)
+            for (int naz = 0; naz < Nphi; ++naz) {
+                const double xc = c->Rmed[nrad] * cos(c->dphi * (double)naz);
+                const double yc = c->Rmed[nrad] * sin(c->dphi * (double)naz);
+                const double distance_measured = sqrt((x - xc) * (x - xc) + (y - yc) * (y - yc));
+                const double distance = fmax(distance_measured, min_dist);
+                const double roverd = distance < R_star ? 1.0 : R_star / distance;
+                const double HoverR = c->scale_height[IDX(c, nrad, naz)] / c->Rmed[nrad]; /* ASPECTRATIO */
+                const double tau_eff = c->tau_eff[IDX(c, nrad, naz)];
+                const double eps = 0.5;
+                const double dlogH_dlogr = 9.0 / 7.0; /* Chiang & Goldreich (1997) */
+                const double W_G = 0.4 * roverd + HoverR * (dlogH_dlogr - 1.0);
+                const double T_irrad_pow4 = (1.0 - eps) * (Ts2 * Ts2) * (roverd * roverd) * W_G;
+                const double qplus = 2.0 * d->sigma_sb * T_irrad_pow4 / tau_eff;
+                c->qplus[IDX(c, nrad, naz)] += ramping * qplus;
+            }
+    }
+}
 /* the alpha factor shared by SubStep3 (SourceEuler.cpp:1005-1024) and
  * compute_heating_cooling_for_CFL (:1520-1545) */
 static double substep3_alpha(const orc_ctx *c, double H, double sigma, double energy)
@@ -1673,6 +1739,11 @@ static void substep3(orc_ctx *c, double current_time, double dt)
     compute_temperature(c);
     calculate_qminus(c, current_time);
     calculate_qplus(c);
+    if (c->heating_star) {
+        if (!c->d.cooling_surface)
+            kappa_eff(c);
+        irradiation(c, current_time);
+    }
 #pragma omp parallel for if (c->big)
     for (int nr = 1; nr < Nr - 1; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {
@@ -1717,6 +1788,11 @@ static void compute_heating_cooling_for_CFL(orc_ctx *c)
         c->d.cooling_beta = beta;
     }
     calculate_qplus(c);
+    if (c->heating_star) {
+        if (!c->d.cooling_surface)
+            kappa_eff(c);
+        irradiation(c, c->clk.time);
+    }
     const int Nr = c->nr - 1, Nphi = c->nphi;
     for (int nr = 1; nr < Nr; ++nr)
         for (int naz = 0; naz < Nphi; ++naz) {

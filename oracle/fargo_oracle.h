@@ -37,6 +37,8 @@ int orc_set_bodies(orc_ctx *c, int32_t n, const double *x, const double *y, cons
 int orc_set_bodies_midstep(orc_ctx *c, int32_t n, const double *x, const double *y, const double *mass,
                            const double *rsm);
 int orc_init_physics(orc_ctx *c);
+int orc_set_body_irradiation(orc_ctx *c, int32_t n, const double *temperature, const double *radius,
+                             const double *rampup_time);
 int orc_disk_on_body_accel(orc_ctx *c, double x, double y, double r_object, double smoothing_fixed,
                            double cubic_smoothing_radius, double out[4]);
 int orc_cfl(orc_ctx *c, double *dt_local);

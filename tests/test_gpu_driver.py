@@ -99,7 +99,7 @@ def test_temperature_test_setup_file(tmp_path):
     out = tmp_path / "tt"
     lines = [("OutputDir: " + str(out)) if l.startswith("OutputDir") else l for l in cfgtext.splitlines()]
     cfg.write_text("\n".join(lines) + "\n")
-    r = subprocess.run([BIN, "-q", "start", str(cfg)], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([BIN, "-q", "start", str(cfg)], capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stderr
     out = str(out) + "/"
     assert open(out + "snapshots/list.txt").read().split()[-1] == "10"
@@ -125,3 +125,21 @@ def test_temperature_test_setup_file(tmp_path):
     assert np.max(Tdiff[radial_range]) < 0.01
     densnum = np.fromfile(out + "snapshots/10/Sigma.dat").reshape(nr, -1).mean(1) * Sigma0
     assert np.max((np.abs(densnum - dens) / dens)[radial_range]) < 0.01
+
+
+def test_irradiation_setup_file(tmp_path):
+    """test/irradiation/angelo.yml through the driver on the GPU (168 k leapfrog steps of a 200 x 2 grid),
+    checked with test/irradiation/check_results.py's constants and threshold."""
+    from tests.test_oracle_known_answers import _irradiation_deviation
+    cfgtext = open(os.path.join(GOLDEN, "setups", "irradiation_angelo.yml")).read()
+    cfg = tmp_path / "config.yml"
+    out = tmp_path / "irr"
+    lines = [("OutputDir: " + str(out)) if l.startswith("OutputDir") else l for l in cfgtext.splitlines()]
+    cfg.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([BIN, "-q", "start", str(cfg)], capture_output=True, text=True, timeout=360)
+    assert r.returncode == 0, r.stderr
+    out = str(out) + "/"
+    ri = np.genfromtxt(out + "used_rad.dat")
+    rc = 2.0 / 3.0 * (ri[1:] ** 3 - ri[:-1] ** 3) / (ri[1:] ** 2 - ri[:-1] ** 2)
+    T = np.fromfile(out + "snapshots/10/Temperature.dat").reshape(len(rc), -1).mean(1)
+    assert _irradiation_deviation(rc, T) < 0.03

@@ -313,3 +313,33 @@ def test_temperature_test_setup_parity(product, oracle):
     criterion on this setup (tests/test_oracle_known_answers.py)."""
     d = setups.temperature_test(product)
     _check(run_pair(product, oracle, d, 400, amp=0.0), ("sigma", "vrad", "vazi", "energy"))
+
+
+def test_irradiation_parity(product, oracle):
+    """irradiation_single (SourceEuler.cpp:538-612) in SubStep3: the reference's irradiation setup (200 x 2,
+    per-cell kernels) for 300 steps, and a planet disk at 44 x 320 (marching kernel) heated by the star and
+    by a hot planet with a ramp-up time."""
+    from fargocpt_amd import driver
+    d, bodies, irr = setups.irradiation_test(product)
+    outs = []
+    for L in (product, oracle):
+        ctx = driver.make_context(L, d, bodies=bodies, irradiation=irr)
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        dts = S.run(300)
+        outs.append((S.gather(), dts))
+        ctx.close()
+    _check(outs, ("sigma", "vrad", "vazi", "energy"))
+    d = setups.planet_disk(product, 44, 320, adiabatic=True)
+    d.cooling_surface, d.opacity = 1, B.OPACITY_LIN
+    x, y, m = setups.jupiter_bodies(d)
+    irr = ([5800.0 / setups.TEMP0_K, 1500.0 / setups.TEMP0_K], [4.65e-3, 4.7e-4], [0.0, 0.05])
+    outs = []
+    for L in (product, oracle):
+        ctx = driver.make_context(L, d, bodies=(x, y, m, [0.0, 0.05]), irradiation=irr)
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        dts = S.run(25)
+        outs.append((S.gather(), dts))
+        ctx.close()
+    _check(outs, ("sigma", "vrad", "vazi", "energy"))

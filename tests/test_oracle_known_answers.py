@@ -135,3 +135,46 @@ def test_temperature_test_reference_criterion(product, oracle):
     assert np.max(Tdiff[radial_range]) < 0.01
     densnum = sig.mean(axis=1) * Sigma0
     assert np.max((np.abs(densnum - dens) / dens)[radial_range]) < 0.01
+
+
+def test_irradiation_test_reference_criterion(product, oracle):
+    """test/irradiation (angelo.yml + check_results.py): a passive disk in equilibrium between stellar
+    irradiation and thermal cooling (D'Angelo & Marzari 2012).  The reference's criterion with its own
+    constants: at snapshot 10 the temperature deviates by < 3 % from the analytic profile for 2 < r < 15.
+    Pins irradiation_single, the irradiated tau_eff and Opacity: Constant."""
+    from fargocpt_amd import driver, setups
+    d, bodies, irradiation = setups.irradiation_test(product)
+    ctx = driver.make_context(oracle, d, bodies=bodies, irradiation=irradiation)
+    S = driver.SlabSet([ctx])
+    S.prepare()
+    while ctx.clock.time < 62800.0 - 1e-9:
+        S.step()
+    radii = product.radii(d)
+    ri, rs = radii[:d.nr_global], radii[1:d.nr_global + 1]
+    r = 2.0 / 3.0 * (rs ** 3 - ri ** 3) / (rs ** 2 - ri ** 2)
+    sig, e = ctx.download(B.F_SIGMA), ctx.download(B.F_ENERGY)
+    ctx.close()
+    assert _irradiation_deviation(r, (d.mu / d.Rgas * (d.adiabatic_index - 1.0) * e / sig).mean(axis=1)) < 0.03
+
+
+def _irradiation_deviation(r, T_code):
+    # --- test/irradiation/check_results.py, verbatim constants ---
+    T0 = 106700.1843026118
+    Tnum = T_code * T0
+    mu = 2.35
+    m_H = 1.66054e-24
+    k_B = 1.38065e-16
+    l0 = 14959787070000
+    rcgs = r * l0
+    m0 = 1.98847e+33
+    G = 6.6743e-08
+    eta = 2 / 7
+    eps = 0.5
+    Rs = 4.6505e-05 * l0
+    Ts = 100000
+    htheo = (eta * (1 - eps) * (k_B * Ts / (mu * m_H)) ** 4 * (Rs / (G * m0)) ** 4 * (rcgs / Rs) ** 2) ** (1 / 7)
+    WG = 0.4 * (Rs / rcgs) + htheo * eta
+    Ttheo = Ts * np.sqrt(Rs / rcgs) * ((1 - eps) * WG) ** (1 / 4)
+    Tdiff = np.abs(Tnum - Ttheo) / Ttheo
+    radial_range = np.logical_and(r > 2, r < 15)
+    return np.max(Tdiff[radial_range])
