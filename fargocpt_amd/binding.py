@@ -29,7 +29,8 @@ INTEGRATOR_EULER, INTEGRATOR_LEAPFROG = 0, 1
 DAMP_NONE, DAMP_REFERENCE, DAMP_ZERO, DAMP_MEAN = range(4)
 IC_PROFILE, IC_SPREADING_RING, IC_SHOCKTUBE = range(3)
 (F_SIGMA, F_VRAD, F_VAZI, F_ENERGY, F_PRESSURE, F_SOUNDSPEED, F_SCALE_HEIGHT, F_VISCOSITY,
- F_TEMPERATURE, F_POTENTIAL, F_SIGMA0, F_VRAD0, F_VAZI0, F_ENERGY0, F_QPLUS, F_QMINUS) = range(16)
+ F_TEMPERATURE, F_POTENTIAL, F_SIGMA0, F_VRAD0, F_VAZI0, F_ENERGY0, F_QPLUS, F_QMINUS,
+ F_VISC_CFAC_PHI, F_VISC_CFAC_R) = range(18)
 VECTOR_FIELDS = (F_VRAD, F_VRAD0)
 
 ERRORS = {-1: "FCPT_EINVAL", -2: "FCPT_ENOMEM", -3: "FCPT_EHIP", -4: "FCPT_ESPLIT", -5: "FCPT_ENODEV", -6: "FCPT_ESHEAR"}

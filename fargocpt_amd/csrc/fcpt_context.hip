@@ -366,8 +366,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
                   sizeof(fcpt_desc), d->abi_version, FCPT_ABI_VERSION);
         return FCPT_EINVAL;
     }
-    if (d->stabilize_viscosity != 0) {
-        set_error("StabilizeViscosity != 0 is not supported");
+    if (d->stabilize_viscosity < 0 || d->stabilize_viscosity > 2) {
+        set_error("StabilizeViscosity must be 0, 1 or 2");
         return FCPT_EINVAL;
     }
     if (!d->body_force_from_potential) {
@@ -476,6 +476,10 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
             t6[i] = std::sqrt(d->G * d->hydro_center_mass / (rm * rm * rm));
         }
         if (!rc) rc = dev_upload(c, &P.g_omk.p, t6);
+        std::vector<double> t7(nr + 2, 0.0);
+        for (int i = 0; i <= nr; ++i)
+            t7[i] = std::pow(g.Rinf[i], 3);
+        if (!rc) rc = dev_upload(c, &P.g_ra3.p, t7);
         std::vector<RadRow> rt(nr + 2);
         for (int k = -1; k <= nr; ++k) {
             const bool open = k > 0 && k < nr;
@@ -608,6 +612,10 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     AL(cfl_part, (size_t)(nr + 256) * (size_t)((nphi + 255) / 256 + 1))
     P.ring_pstride = nphi / 32 + 4;
     AL(ring_part, (size_t)nr * P.ring_pstride)
+    P.stabilize = d->stabilize_viscosity;
+    if (P.stabilize) {
+        AL(cfac_phi, ns) AL(cfac_r, ns)
+    }
 #undef AL
     if (!rc && hipHostMalloc((void **)&c->h_clk, sizeof(DevClock)) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -636,6 +644,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     c->grid[FCPT_F_ENERGY0] = P.energy0;
     c->grid[FCPT_F_QPLUS] = P.qplus;
     c->grid[FCPT_F_QMINUS] = P.qminus;
+    c->grid[FCPT_F_VISC_CFAC_PHI] = P.cfac_phi; // null unless StabilizeViscosity
+    c->grid[FCPT_F_VISC_CFAC_R] = P.cfac_r;
 
     P.zero_no_ghost = c->s.zero_no_ghost;
     P.one_no_ghost_vr = c->s.one_no_ghost_vr;
@@ -784,6 +794,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         c->fused_source = e[0] != '0';
     if (const char *e = getenv("FCPT_MARCH_SOURCE"))
         c->march_source = e[0] != '0';
+    if (c->P.stabilize) // the pseudo-implicit viscosity lives in the per-loop kernels only
+        c->fused_source = c->march_source = false;
     {
         bool adi_march = c->P.adiabatic && c->fused_source && c->march_source && c->P.nphi >= 128;
         if (const char *e = getenv("FCPT_MARCH_SOURCE_ADI"))
@@ -874,7 +886,7 @@ static size_t grid_count(const fcpt_ctx *c, int32_t f)
 
 int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
 {
-    if (!c || !host || f < 0 || f >= FCPT_F_COUNT) {
+    if (!c || !host || f < 0 || f >= FCPT_F_COUNT || !c->grid[f]) {
         set_error("bad argument to fcpt_upload");
         return FCPT_EINVAL;
     }
@@ -887,7 +899,7 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
 
 int fcpt_download(fcpt_ctx *c, int32_t f, double *host)
 {
-    if (!c || !host || f < 0 || f >= FCPT_F_COUNT) {
+    if (!c || !host || f < 0 || f >= FCPT_F_COUNT || !c->grid[f]) {
         set_error("bad argument to fcpt_download");
         return FCPT_EINVAL;
     }
@@ -901,7 +913,7 @@ int fcpt_download(fcpt_ctx *c, int32_t f, double *host)
 
 int fcpt_device_ptr(fcpt_ctx *c, int32_t f, void **dptr, uint64_t *count)
 {
-    if (!c || !dptr || f < 0 || f >= FCPT_F_COUNT)
+    if (!c || !dptr || f < 0 || f >= FCPT_F_COUNT || !c->grid[f])
         return FCPT_EINVAL;
     *dptr = c->grid[f];
     if (count)

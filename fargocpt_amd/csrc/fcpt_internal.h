@@ -144,6 +144,10 @@ struct Dev {
     double *sigma0, *vrad0, *vazi0, *energy0;
     // source-step scratch
     double *qr, *qphi, *divv, *trr, *tpp, *trp /* (nr+1) rows */, *qplus, *qminus;
+    // StabilizeViscosity (viscosity.cpp:256-348): correction factors c1_phi, c1_r; null when it is 0
+    double *cfac_phi, *cfac_r;
+    CArr g_ra3;    // pow(Rinf[i], 3)
+    int stabilize; // 0: off, 1: damp the viscous velocity update, 2: limit the time step
     // transport: momenta / density / energy, two sets (A: after pass 1, B: radial + final)
     double *rmpA, *rmmA, *lpA, *lmA, *sigA, *eA;
     double *rmpB, *rmmB, *lpB, *lmB, *sigB, *eB;

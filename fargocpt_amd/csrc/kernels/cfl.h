@@ -68,6 +68,11 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
             }
             s = dmax(s, invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 + invdt5 * invdt5 +
                             invdt6 * invdt6);
+            if (P.stabilize == 2) { // cfl.cpp:331-351: dt_cell = min(dt_cell, -CFL / c) == CFL / sqrt(max(sum, c^2)), c < 0
+                const double c = dmin(P.cfac_phi[IDX(i, j)], P.cfac_r[IDX(i, j)]);
+                if (c < 0.0)
+                    s = dmax(s, c * c);
+            }
             vr0 = vr1;
         }
     }

@@ -177,6 +177,8 @@ void launch_stress(const Dev &P, hipStream_t st)
 {
     LAUNCH2D(KID_STRESS_DIAG, k_stress_diag, P.nr, P);
     LAUNCH2D(KID_STRESS_RPHI, k_stress_rphi, P.nr - 1, P);
+    if (P.stabilize)
+        LAUNCH2D(KID_STRESS_RPHI, k_visc_factors, P.nr - 1, P);
 }
 
 void launch_viscous_update(const Dev &P, hipStream_t st)
@@ -429,7 +431,8 @@ void launch_cfl(const Dev &P, int apply_policy, hipStream_t st)
 {
     // one block per ring: mean and cells in one pass (even Nphi up to 512 * CFL_MAXP; the isothermal
     // viscosity and sound speed per ring, or the lazily derived ones of the ideal EOS)
-    bool rings = (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 512 * CFL_MAXP && (!P.adiabatic || P.lazy_derived);
+    bool rings = (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 512 * CFL_MAXP && (!P.adiabatic || P.lazy_derived) &&
+                 P.stabilize != 2;
     if (const char *e = getenv("FCPT_CFL_RINGS"))
         rings = rings && e[0] != '0';
     if (rings) {

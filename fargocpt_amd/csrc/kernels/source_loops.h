@@ -286,6 +286,53 @@ template <bool ROWU> __global__ void k_stress_rphi(const Dev P)
                                  P.sigma[IDX(i - 1, jp)]);
     P.trp[IDX(i, j)] = nu * sigma * drp;
 }
+// VISCOSITY_SIGMA_RP (viscosity.cpp:228-252): nu Sigma averaged over the four cells around the corner; rows 0 and Nr hold 0
+__device__ __forceinline__ double nusig_rp(const Dev &P, int i, int j, int jp)
+{
+    if (i < 1 || i >= P.nr)
+        return 0.0;
+    const double nu = 0.25 * (P.viscosity[IDX(i, j)] + P.viscosity[IDX(i - 1, j)] + P.viscosity[IDX(i, jp)] +
+                              P.viscosity[IDX(i - 1, jp)]);
+    const double sigma =
+        0.25 * (P.sigma[IDX(i, j)] + P.sigma[IDX(i - 1, j)] + P.sigma[IDX(i, jp)] + P.sigma[IDX(i - 1, jp)]);
+    return nu * sigma;
+}
+// viscosity/viscosity.cpp:256-348: correction factors of the pseudo-implicit viscosity (StabilizeViscosity 1|2),
+// rows 1..Nr-1.  Not on the marching path: three small kernels extra per kick.
+template <bool ROWU> __global__ void k_visc_factors(const Dev P)
+{
+    CELL(1, P.nr - 1);
+    const int jp = JPREV, jn = JNEXT;
+    const double NuSig_rp = nusig_rp(P, i, j, jp);
+    const double NuSig_rp_ip = nusig_rp(P, i + 1, j, jp);
+    const double NuSig_rp_jp = nusig_rp(P, i, jn, j);
+    const double sg = P.sigma[IDX(i, j)], sg_jm = P.sigma[IDX(i, jp)], sg_im = P.sigma[IDX(i - 1, j)];
+    const double NuSigma = P.viscosity[IDX(i, j)] * sg;
+    const double NuSigma_jm = P.viscosity[IDX(i, jp)] * sg_jm;
+    const double NuSigma_im = P.viscosity[IDX(i - 1, j)] * sg_im;
+    const double Ra = P.Rinf[i], rs = P.Rsup[i];
+    const double TwoDiffRaSq = 2.0 / (rs * rs - Ra * Ra);
+    const double FourThirdInvRbInvdphiSq = 4.0 / 3.0 / P.Rmed[i] * P.invdphi * P.invdphi;
+    const double a0 = NuSig_rp * P.g_ra3[i] * P.InvDiffRmed[i];
+    const double a1 = NuSig_rp_ip * P.g_ra3[i + 1] * P.InvDiffRmed[i + 1];
+    const double cphi_rp = -P.InvRmed[i] * TwoDiffRaSq * (a1 + a0);
+    const double cphi_pp = -FourThirdInvRbInvdphiSq * (NuSigma + NuSigma_jm);
+    const double sigma_avg_phi = 0.5 * (sg + sg_jm);
+    P.cfac_phi[IDX(i, j)] = (cphi_rp + cphi_pp) / (sigma_avg_phi * P.Rmed[i]);
+    const double sigma_avg_r = 0.5 * (sg + sg_im);
+    const double cr_rp = -(NuSig_rp_jp + NuSig_rp) / (P.dphi * P.dphi * Ra);
+    const double cr_pp_1 = 2.0 * NuSigma * (0.5 * P.InvRmed[i] + 1.0 / 3.0 * Ra * P.InvDiffRsupRb[i]);
+    const double cr_pp_2 = 2.0 * NuSigma_im * (0.5 * P.InvRmed[i - 1] - 1.0 / 3.0 * Ra * P.InvDiffRsupRb[i - 1]);
+    const double cr_rr_1 = P.Rmed[i] * 2.0 * NuSigma * (-P.InvDiffRsup[i] + 1.0 / 3.0 * Ra * P.InvDiffRsupRb[i]);
+    const double cr_rr_2 =
+        -1.0 * P.Rmed[i - 1] * 2.0 * NuSigma_im * (P.InvDiffRsup[i - 1] - 1.0 / 3.0 * Ra * P.InvDiffRsupRb[i - 1]);
+    const double cr_pp = -0.5 * (cr_pp_1 + cr_pp_2);
+    const double cr_rr = P.InvDiffRmed[i] * (cr_rr_1 + cr_rr_2);
+    const double Rmed_mid = 0.5 * (P.Rmed[i] + P.Rmed[i - 1]);
+    P.cfac_r[IDX(i, j)] = P.radial_viscosity_factor * (cr_rr + cr_rp + cr_pp) / (sigma_avg_r * Rmed_mid);
+}
+// viscosity/viscosity.cpp:386-391|413-417: corr = 1 / (max(1 + dt c, 0) - dt c)
+__device__ __forceinline__ double visc_corr(double dt, double c) { return 1.0 / (dmax(1.0 + dt * c, 0.0) - dt * c); }
 // viscosity/viscosity.cpp:368-394: v_phi update
 template <bool ROWU> __global__ void k_visc_va(const Dev P)
 {
@@ -294,10 +341,12 @@ template <bool ROWU> __global__ void k_visc_va(const Dev P)
     const int jp = JPREV;
     const double sigma_avg = 0.5 * (P.sigma[IDX(i, j)] + P.sigma[IDX(i, jp)]);
     const double ra1 = P.Rinf[i + 1], ra0 = P.Rinf[i];
-    const double dVp = dt * P.InvRmed[i] / (sigma_avg) *
-                       ((2.0 / (ra1 * ra1 - ra0 * ra0)) *
+    double dVp = dt * P.InvRmed[i] / (sigma_avg) *
+                 ((2.0 / (ra1 * ra1 - ra0 * ra0)) *
                             (ra1 * ra1 * P.trp[IDX(i + 1, j)] - ra0 * ra0 * P.trp[IDX(i, j)]) +
                         (P.tpp[IDX(i, j)] - P.tpp[IDX(i, jp)]) * P.invdphi);
+    if (P.stabilize == 1)
+        dVp *= visc_corr(dt, P.cfac_phi[IDX(i, j)]);
     P.vazi[IDX(i, j)] += dVp;
 }
 // viscosity/viscosity.cpp:396-421: v_r update
@@ -307,10 +356,12 @@ template <bool ROWU> __global__ void k_visc_vr(const Dev P)
     const double dt = P.clk->dt;
     const int jn = JNEXT;
     const double sigma_avg = 0.5 * (P.sigma[IDX(i, j)] + P.sigma[IDX(i - 1, j)]);
-    const double dVr = dt / (sigma_avg)*P.radial_viscosity_factor * 2.0 / (P.Rmed[i] + P.Rmed[i - 1]) *
+    double dVr = dt / (sigma_avg)*P.radial_viscosity_factor * 2.0 / (P.Rmed[i] + P.Rmed[i - 1]) *
                        ((P.Rmed[i] * P.trr[IDX(i, j)] - P.Rmed[i - 1] * P.trr[IDX(i - 1, j)]) * P.InvDiffRmed[i] +
                         (P.trp[IDX(i, jn)] - P.trp[IDX(i, j)]) * P.invdphi -
                         0.5 * (P.tpp[IDX(i, j)] + P.tpp[IDX(i - 1, j)]));
+    if (P.stabilize == 1)
+        dVr *= visc_corr(dt, P.cfac_r[IDX(i, j)]);
     P.vrad[IDX(i, j)] += dVr;
 }
 

@@ -85,7 +85,11 @@ enum {
     FCPT_F_ENERGY0 = 13,
     FCPT_F_QPLUS = 14,
     FCPT_F_QMINUS = 15,
-    FCPT_F_COUNT = 16
+    /* VISCOSITY_CORRECTION_FACTOR_PHI|R (viscosity.cpp:256-348); only with StabilizeViscosity 1|2,
+     * FCPT_EINVAL otherwise */
+    FCPT_F_VISC_CFAC_PHI = 16,
+    FCPT_F_VISC_CFAC_R = 17,
+    FCPT_F_COUNT = 18
 };
 
 /*
@@ -127,7 +131,7 @@ typedef struct fcpt_desc {
     double viscous_alpha;           /* ViscousAlpha */
     double constant_viscosity;      /* ConstantViscosity */
     double radial_viscosity_factor; /* RadialViscosityFactor */
-    int32_t stabilize_viscosity;    /* StabilizeViscosity: only 0 is supported */
+    int32_t stabilize_viscosity;    /* StabilizeViscosity: 0, 1 (damped viscous update) or 2 (dt limit) */
     int32_t artificial_viscosity;   /* ArtificialViscosity */
     double artificial_viscosity_factor;       /* ArtificialViscosityFactor */
     int32_t artificial_viscosity_dissipation; /* ArtificialViscosityDissipation */

@@ -11,11 +11,15 @@
  * GSL, which is absent, and links the whole program: yaml-cpp, LLNL units,
  * REBOUND, MPI).  The oracle is therefore pinned by the reference's own
  * known-answer tests -- test/shockTube (analytic_shock.dat + thresholds of
- * check_results.py:18-23) and test/spreading_ring (calc_deviation.py:43-66) --
- * see tests/test_oracle_known_answers.py.
+ * check_results.py:18-23), test/spreading_ring (calc_deviation.py:43-66),
+ * test/TemperatureTest and test/irradiation (their check_results.py) --
+ * see tests/test_oracle_known_answers.py.  PARITY UNPINNED for one switch:
+ * StabilizeViscosity 1|2 is never on in the reference's tests; its correction
+ * factors are checked against the Jacobian diagonal of the viscous force
+ * (same file), where they are applied is a restatement only.
  *
  * Out of scope (not restated): N-body integration, self-gravity, FLD, dust,
- * cooling terms (Q- is identically 0), variable-gamma EOS, StabilizeViscosity,
+ * S-curve cooling and the Bell opacity, variable-gamma EOS,
  * BodyForceFromPotential=no, composite BCs (custom / centerofmass), mass-flow
  * bookkeeping (MassDelta).
  */
@@ -48,6 +52,7 @@ struct orc_ctx {
     double *pressure, *soundspeed, *scale_height, *viscosity, *temperature, *potential;
     double *sigma0, *vrad0, *vazi0, *energy0;
     double *qr, *qphi, *divv, *trr, *tpp, *trp /* vector */, *qplus, *qminus, *density_int;
+    double *nusig, *nusig_rp /* vector */, *cfac_phi, *cfac_r; /* StabilizeViscosity (viscosity.cpp:256-348) */
     double *tau_eff; /* kappa_eff (compute.cpp:41-87); 0 without surface cooling */
     double btemp[FCPT_MAX_BODIES], bradius[FCPT_MAX_BODIES], bramp[FCPT_MAX_BODIES]; /* irradiating bodies */
     int heating_star; /* parameters::heating_star_enabled */
@@ -555,7 +560,7 @@ int orc_create(const fcpt_desc *d, const double *radii, orc_ctx **out)
         return FCPT_EINVAL;
     if (d->struct_size != sizeof(fcpt_desc) || d->abi_version != FCPT_ABI_VERSION)
         return FCPT_EINVAL;
-    if (d->stabilize_viscosity != 0 || !d->body_force_from_potential)
+    if (d->stabilize_viscosity < 0 || d->stabilize_viscosity > 2 || !d->body_force_from_potential)
         return FCPT_EINVAL;
     if ((d->cooling_surface || d->cooling_beta) && d->eos != FCPT_EOS_IDEAL)
         return FCPT_EINVAL;
@@ -615,6 +620,10 @@ int orc_create(const fcpt_desc *d, const double *radii, orc_ctx **out)
     c->qplus = dalloc(ns);
     c->qminus = dalloc(ns);
     c->density_int = dalloc(ns);
+    c->nusig = dalloc(ns);
+    c->nusig_rp = dalloc(nv);
+    c->cfac_phi = dalloc(ns);
+    c->cfac_r = dalloc(ns);
     c->tau_eff = dalloc(ns);
     c->rmp = dalloc(ns);
     c->rmm = dalloc(ns);
@@ -652,7 +661,7 @@ int orc_destroy(orc_ctx *c)
                      &c->pressure,   &c->soundspeed, &c->scale_height, &c->viscosity, &c->temperature,
                      &c->potential,  &c->sigma0,    &c->vrad0,       &c->vazi0,       &c->energy0,
                      &c->qr,         &c->qphi,      &c->divv,        &c->trr,         &c->tpp,
-                     &c->trp,        &c->qplus,     &c->qminus,      &c->density_int, &c->tau_eff,
+                     &c->trp,        &c->qplus,     &c->qminus,      &c->density_int, &c->tau_eff, &c->nusig, &c->nusig_rp, &c->cfac_phi, &c->cfac_r,
                      &c->rmp,        &c->rmm,       &c->lp,          &c->lm,          &c->vres,
                      &c->vmean,      &c->work,      &c->qrstar,      &c->densstar,    &c->tempshift,
                      &c->dq,         &c->cfl_vmean, &c->cfl_vres};
@@ -707,6 +716,8 @@ static double *field_ptr(orc_ctx *c, int32_t f, size_t *n)
     case FCPT_F_ENERGY0: return c->energy0;
     case FCPT_F_QPLUS: return c->qplus;
     case FCPT_F_QMINUS: return c->qminus;
+    case FCPT_F_VISC_CFAC_PHI: return c->d.stabilize_viscosity ? c->cfac_phi : NULL;
+    case FCPT_F_VISC_CFAC_R: return c->d.stabilize_viscosity ? c->cfac_r : NULL;
     default: return NULL;
     }
 }
@@ -1432,7 +1443,7 @@ static void recalculate_viscosity(orc_ctx *c)
     update_viscosity(c);
 }
 
-/* viscosity/viscosity.cpp:139-254 compute_viscous_stress_tensor (StabilizeViscosity 0) */
+/* viscosity/viscosity.cpp:139-254 compute_viscous_stress_tensor, :256-348 the StabilizeViscosity factors */
 static void compute_viscous_stress_tensor(orc_ctx *c)
 {
     const int Nr = c->nr, Nphi = c->nphi;
@@ -1480,6 +1491,50 @@ static void compute_viscous_stress_tensor(orc_ctx *c)
             const double sigma = 0.25 * (c->sigma[IDX(c, nr, naz)] + c->sigma[IDX(c, nr - 1, naz)] +
                                          c->sigma[IDX(c, nr, naz_prev)] + c->sigma[IDX(c, nr - 1, naz_prev)]);
             c->trp[IDX(c, nr, naz)] = nu * sigma * drp;
+            c->nusig_rp[IDX(c, nr, naz)] = nu * sigma; /* VISCOSITY_SIGMA_RP */
+        }
+    if (!c->d.stabilize_viscosity)
+        return;
+    /* viscosity.cpp:256-348: correction factors of the pseudo-implicit viscosity */
+    const double dphi = c->dphi;
+#pragma omp parallel for if (c->big)
+    for (int nr = 0; nr < Nr; ++nr)
+        for (int naz = 0; naz < Nphi; ++naz)
+            c->nusig[IDX(c, nr, naz)] = c->viscosity[IDX(c, nr, naz)] * c->sigma[IDX(c, nr, naz)]; /* VISCOSITY_SIGMA */
+#pragma omp parallel for if (c->big)
+    for (int nr = 1; nr < Nr; ++nr)
+        for (int naz = 0; naz < Nphi; ++naz) {
+            const int naz_prev = (naz == 0 ? Nphi - 1 : naz - 1);
+            const int naz_next = (naz == Nphi - 1 ? 0 : naz + 1);
+            const double NuSig_rp = c->nusig_rp[IDX(c, nr, naz)];
+            const double NuSig_rp_ip = c->nusig_rp[IDX(c, nr + 1, naz)];
+            const double NuSig_rp_jp = c->nusig_rp[IDX(c, nr, naz_next)];
+            const double NuSigma = c->nusig[IDX(c, nr, naz)];
+            const double NuSigma_jm = c->nusig[IDX(c, nr, naz_prev)];
+            const double NuSigma_im = c->nusig[IDX(c, nr - 1, naz)];
+            const double Ra = c->Rinf[nr], Rap = c->Rinf[nr + 1];
+            const double TwoDiffRaSq = 2.0 / (c->Rsup[nr] * c->Rsup[nr] - c->Rinf[nr] * c->Rinf[nr]);
+            const double FourThirdInvRbInvdphiSq = 4.0 / 3.0 / c->Rmed[nr] * c->invdphi * c->invdphi;
+            const double Ra3NuSigmaInvDiffRmed = NuSig_rp * pow(Ra, 3) * c->InvDiffRmed[nr];
+            const double Ra3NuSigmaInvDiffRmed_p = NuSig_rp_ip * pow(Rap, 3) * c->InvDiffRmed[nr + 1];
+            const double cphi_rp = -c->InvRmed[nr] * TwoDiffRaSq * (Ra3NuSigmaInvDiffRmed_p + Ra3NuSigmaInvDiffRmed);
+            const double cphi_pp = -FourThirdInvRbInvdphiSq * (NuSigma + NuSigma_jm);
+            const double sigma_avg_phi = 0.5 * (c->sigma[IDX(c, nr, naz)] + c->sigma[IDX(c, nr, naz_prev)]);
+            c->cfac_phi[IDX(c, nr, naz)] = (cphi_rp + cphi_pp) / (sigma_avg_phi * c->Rmed[nr]);
+            const double sigma_avg_r = 0.5 * (c->sigma[IDX(c, nr, naz)] + c->sigma[IDX(c, nr - 1, naz)]);
+            const double cr_rp = -(NuSig_rp_jp + NuSig_rp) / (dphi * dphi * Ra);
+            const double cr_pp_1 = 2.0 * NuSigma * (0.5 * c->InvRmed[nr] + 1.0 / 3.0 * Ra * c->InvDiffRsupRb[nr]);
+            const double cr_pp_2 =
+                2.0 * NuSigma_im * (0.5 * c->InvRmed[nr - 1] - 1.0 / 3.0 * Ra * c->InvDiffRsupRb[nr - 1]);
+            const double cr_rr_1 =
+                c->Rmed[nr] * 2.0 * NuSigma * (-c->InvDiffRsup[nr] + 1.0 / 3.0 * Ra * c->InvDiffRsupRb[nr]);
+            const double cr_rr_2 = -1.0 * c->Rmed[nr - 1] * 2.0 * NuSigma_im *
+                                   (c->InvDiffRsup[nr - 1] - 1.0 / 3.0 * Ra * c->InvDiffRsupRb[nr - 1]);
+            const double cr_pp = -0.5 * (cr_pp_1 + cr_pp_2);
+            const double cr_rr = c->InvDiffRmed[nr] * (cr_rr_1 + cr_rr_2);
+            const double Rmed_mid = 0.5 * (c->Rmed[nr] + c->Rmed[nr - 1]);
+            c->cfac_r[IDX(c, nr, naz)] =
+                c->d.radial_viscosity_factor * (cr_rr + cr_rp + cr_pp) / (sigma_avg_r * Rmed_mid);
         }
 }
 /* viscosity/viscosity.cpp:355-426 update_velocities_with_viscosity */
@@ -1497,7 +1552,12 @@ static void update_velocities_with_viscosity(orc_ctx *c, double dt)
                 ((2.0 / (ra1 * ra1 - ra0 * ra0)) *
                      (ra1 * ra1 * c->trp[IDX(c, nr + 1, naz)] - ra0 * ra0 * c->trp[IDX(c, nr, naz)]) +
                  (c->tpp[IDX(c, nr, naz)] - c->tpp[IDX(c, nr, naz_prev)]) * c->invdphi);
-            c->vazi[IDX(c, nr, naz)] += dVp;
+            double dVp_ = dVp;
+            if (c->d.stabilize_viscosity == 1) { /* viscosity.cpp:386-391 */
+                const double cphi = c->cfac_phi[IDX(c, nr, naz)];
+                dVp_ *= 1.0 / (fmax(1.0 + dt * cphi, 0.0) - dt * cphi);
+            }
+            c->vazi[IDX(c, nr, naz)] += dVp_;
         }
 #pragma omp parallel for if (c->big)
     for (int nr = c->s.one_no_ghost_vr; nr < c->s.maxmo_no_ghost_vr; ++nr)
@@ -1510,7 +1570,12 @@ static void update_velocities_with_viscosity(orc_ctx *c, double dt)
                      c->InvDiffRmed[nr] +
                  (c->trp[IDX(c, nr, naz_next)] - c->trp[IDX(c, nr, naz)]) * c->invdphi -
                  0.5 * (c->tpp[IDX(c, nr, naz)] + c->tpp[IDX(c, nr - 1, naz)]));
-            c->vrad[IDX(c, nr, naz)] += dVr;
+            double dVr_ = dVr;
+            if (c->d.stabilize_viscosity == 1) { /* viscosity.cpp:413-417 */
+                const double cr = c->cfac_r[IDX(c, nr, naz)];
+                dVr_ *= 1.0 / (fmax(1.0 + dt * cr, 0.0) - dt * cr);
+            }
+            c->vrad[IDX(c, nr, naz)] += dVr_;
         }
 }
 
@@ -2151,8 +2216,13 @@ int orc_cfl(orc_ctx *c, double *dt_local)
             } else {
                 invdt6 = 0.0;
             }
-            const double dt_cell = d->cfl / sqrt(invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 +
-                                                 invdt4 * invdt4 + invdt5 * invdt5 + invdt6 * invdt6);
+            double dt_cell = d->cfl / sqrt(invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 +
+                                           invdt4 * invdt4 + invdt5 * invdt5 + invdt6 * invdt6);
+            if (d->stabilize_viscosity == 2) { /* cfl.cpp:331-351 */
+                const double cc = fmin(c->cfac_phi[IDX(c, nr, naz)], c->cfac_r[IDX(c, nr, naz)]);
+                if (cc != 0.0)
+                    dt_cell = fmin(dt_cell, -d->cfl / cc);
+            }
             if (dt_cell < dt_core)
                 dt_core = dt_cell;
         }

@@ -343,3 +343,51 @@ def test_irradiation_parity(product, oracle):
         outs.append((S.gather(), dts))
         ctx.close()
     _check(outs, ("sigma", "vrad", "vazi", "energy"))
+
+
+@pytest.mark.parametrize("case", ["update_iso", "update_adiabatic_two_slabs", "dt_leapfrog", "dt_radial_factor"])
+def test_stabilize_viscosity(product, oracle, case):
+    """StabilizeViscosity 1 (viscosity.cpp:386-391|413-417: the viscous velocity update is damped where
+    dt c < -1, forced here by stepping with 3x the CFL step) and 2 (cfl.cpp:331-351: dt <= -CFL / c, binding
+    here through the leapfrog's 0.6 on the kinematic limit or a radial viscosity factor): fields, dt history
+    and the correction factors themselves against the oracle, and the switch must change the run."""
+    from fargocpt_amd import driver
+    mode = 1 if case.startswith("update") else 2
+    adiabatic = "adiabatic" in case
+    d = setups.planet_disk(product, 48, 192, adiabatic=adiabatic)
+    d.viscous_alpha, d.constant_viscosity = 0.0, 1.0e-2
+    d.stabilize_viscosity = mode
+    if case == "dt_leapfrog":
+        d.integrator = B.INTEGRATOR_LEAPFROG
+    if case == "dt_radial_factor":
+        d.radial_viscosity_factor = 2.5
+    scale = 3.0 if mode == 1 else 1.0
+    fields = ("sigma", "vrad", "vazi", "energy") if adiabatic else ("sigma", "vrad", "vazi")
+    outs = run_pair(product, oracle, d, 70, nslabs=(2, 1) if "two_slabs" in case else (1, 1), dt_scale=scale)
+    _check(outs, fields)
+    d0 = d.copy()
+    d0.stabilize_viscosity = 0
+    plain, dt_plain = run_pair(product, product, d0, 70, nslabs=(1, 0), dt_scale=scale)[0]
+    if mode == 2:
+        assert outs[0][1][-1] < 0.9 * dt_plain[-1], "the stability limit did not bind"
+    else:
+        assert rel_err(outs[0][0]["vrad"], plain["vrad"]) > 1e-3, "the update was never damped"
+    # the factors (t_data VISCOSITY_CORRECTION_FACTOR_PHI|R) after one more kick
+    facs = []
+    for L in (product, oracle):
+        dd = d.copy()
+        dd.rank, dd.nranks = 0, 1
+        ctx = driver.make_context(L, dd)
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        S.run(3)
+        facs.append((ctx.download(B.F_VISC_CFAC_PHI), ctx.download(B.F_VISC_CFAC_R)))
+        ctx.close()
+    assert rel_err(facs[0][0], facs[1][0]) <= TOL and rel_err(facs[0][1], facs[1][1]) <= TOL
+    assert (facs[0][0][1:] < 0).all() and (facs[0][1][1:] < 0).all()
+    with pytest.raises(B.FcptError):
+        ctx = driver.make_context(product, d0)
+        try:
+            ctx.download(B.F_VISC_CFAC_R)   # only with StabilizeViscosity
+        finally:
+            ctx.close()

@@ -178,3 +178,77 @@ def _irradiation_deviation(r, T_code):
     Tdiff = np.abs(Tnum - Ttheo) / Ttheo
     radial_range = np.logical_and(r > 2, r < 15)
     return np.max(Tdiff[radial_range])
+
+
+def _viscous_accelerations(vr, vp, sigma, nu, Rb, Ra, dphi, radial_factor=1.0):
+    """numpy statement of the viscous force of the Navier-Stokes equations in the conservative
+    form of D'Angelo et al. (2002), on the staggered polar grid: (a_r on rows 1..Nr-1, a_phi on
+    rows 1..Nr-2).  Independent of the oracle's loops; only used to differentiate."""
+    nr, nphi = sigma.shape
+    nxt = lambda a: np.roll(a, -1, axis=1)
+    prv = lambda a: np.roll(a, 1, axis=1)
+    drb = np.diff(Ra)                                   # Rsup - Rinf
+    divv = (vr[1:] * Ra[1:, None] - vr[:-1] * Ra[:-1, None]) / (drb * Rb)[:, None] + (nxt(vp) - vp) / (dphi * Rb[:, None])
+    trr = 2 * nu * sigma * ((vr[1:] - vr[:-1]) / drb[:, None] - divv / 3)
+    tpp = 2 * nu * sigma * ((nxt(vp) - vp) / (dphi * Rb[:, None]) + 0.5 * (vr[1:] + vr[:-1]) / Rb[:, None] - divv / 3)
+    trp = np.zeros((nr + 1, nphi))
+    om = vp / Rb[:, None]
+    nus = nu * np.ones_like(sigma)
+    avg4 = lambda a: 0.25 * (a[1:] + a[:-1] + prv(a)[1:] + prv(a)[:-1])
+    trp[1:nr] = avg4(nus) * avg4(sigma) * (Ra[1:nr, None] * (om[1:] - om[:-1]) / np.diff(Rb)[:, None]
+                                          + (vr[1:nr] - prv(vr)[1:nr]) / (dphi * Ra[1:nr, None]))
+    ra2 = Ra ** 2
+    a_phi = np.zeros_like(sigma)
+    a_phi[1:-1] = ((2 / (ra2[2:nr] - ra2[1:nr - 1]))[:, None] * (ra2[2:nr, None] * trp[2:nr] - ra2[1:nr - 1, None] * trp[1:nr - 1])
+                   + (tpp - prv(tpp))[1:-1] / dphi) / (Rb[1:-1, None] * 0.5 * (sigma + prv(sigma))[1:-1])
+    a_r = np.zeros((nr + 1, nphi))
+    a_r[1:nr] = radial_factor * 2 / (Rb[1:] + Rb[:-1])[:, None] / (0.5 * (sigma[1:] + sigma[:-1])) * (
+        (Rb[1:, None] * trr[1:] - Rb[:-1, None] * trr[:-1]) / np.diff(Rb)[:, None]
+        + (nxt(trp) - trp)[1:nr] / dphi - 0.5 * (tpp[1:] + tpp[:-1]))
+    return a_r, a_phi
+
+
+@pytest.mark.parametrize("alpha", [False, True])
+def test_stabilize_viscosity_factors_are_the_jacobian_diagonal(product, oracle, alpha):
+    """No test of the reference runs StabilizeViscosity != 0 (all setups under test/ set '0'), so the
+    correction factors (viscosity.cpp:256-348) are pinned by what they are meant to be: c1_phi(i,j) =
+    d a_phi(i,j) / d v_phi(i,j) and c1_r(i,j) = d a_r(i,j) / d v_r(i,j) of the viscous acceleration,
+    both negative (the reference asserts that, :338-339).  The accelerations are linear in v, so a
+    finite difference of an independent numpy statement of them gives the diagonal to rounding."""
+    nr, nphi = 30, 36
+    d = setups.planet_disk(product, nr, nphi, damping=False)
+    if not alpha:
+        d.viscous_alpha, d.constant_viscosity = 0.0, 1.0e-3
+    d.stabilize_viscosity = 1
+    d.radial_viscosity_factor = 1.5
+    d.rank, d.nranks = 0, 1
+    radii = oracle.radii(d)
+    fields = oracle.initial_fields(d, radii)
+    rng = np.random.default_rng(5)
+    sigma = fields[0] * (1.0 + 0.3 * rng.random(fields[0].shape))
+    ctx = driver.make_context(oracle, d, fields=(sigma, fields[1], fields[2], fields[3]), radii=radii)
+    S = driver.SlabSet([ctx])
+    S.prepare()
+    sigma_kick = ctx.download(B.F_SIGMA)      # the source step leaves Sigma alone: this is what the kick sees
+    S.step()
+    nu = ctx.download(B.F_VISCOSITY)          # locally isothermal: fixed per ring
+    cphi, cr = ctx.download(B.F_VISC_CFAC_PHI), ctx.download(B.F_VISC_CFAC_R)
+    Ra = np.asarray(radii[:nr + 1])
+    Rb = 2.0 / 3.0 * (Ra[1:] ** 3 - Ra[:-1] ** 3) / (Ra[1:] ** 2 - Ra[:-1] ** 2)   # init.cpp:196
+    dphi = 2 * np.pi / nphi
+    ctx.close()
+    assert (cphi[1:] < 0).all() and (cr[1:] < 0).all()
+    args = (sigma_kick, nu, Rb, Ra, dphi, d.radial_viscosity_factor)
+    jr, jp = np.zeros((nr + 1, nphi)), np.zeros((nr, nphi))
+    zr, zp = np.zeros((nr + 1, nphi)), np.zeros((nr, nphi))
+    for a in range(3):          # the stencils reach one cell: a stride-3 lattice of unit pulses does not self-interact
+        for b in range(3):
+            er, ep = zr.copy(), zp.copy()
+            er[a::3, b::3] = 1.0
+            ep[a::3, b::3] = 1.0
+            jr[a::3, b::3] = _viscous_accelerations(er, zp, *args)[0][a::3, b::3]
+            jp[a::3, b::3] = _viscous_accelerations(zr, ep, *args)[1][a::3, b::3]
+    # c1_phi is stored for rows 1..Nr-1 but a_phi only moves rows 1..Nr-2 (viscosity.cpp:369); in row Nr-1
+    # the factor misses tau_rphi(Nr) = 0, which the update never needs
+    np.testing.assert_allclose(cphi[1:nr - 1], jp[1:nr - 1], rtol=1e-11)
+    np.testing.assert_allclose(cr[1:nr], jr[1:nr], rtol=1e-11)

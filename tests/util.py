@@ -40,6 +40,9 @@ def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=
     if amp:
         fields = perturb(fields, d0, amp)
     for L, ns in zip((lib_a, lib_b), nslabs):
+        if ns == 0:   # only one library wanted
+            outs.append(None)
+            continue
         ctxs = []
         for rank in range(ns):
             dd = d0.copy()
