@@ -64,6 +64,13 @@ def main():
                     help="ideal: BASELINE config 3 physics (energy equation, viscous heating) on the same grid")
     args = ap.parse_args()
 
+    # the contract is ONE JSON line on stdout: libraries that print there (RCCL's version banner at
+    # communicator creation) are sent to stderr for the whole run, the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    os.environ.setdefault("RCCL_LOG_LEVEL", "0")
+
     os.environ.setdefault("OMP_NUM_THREADS", str(affinity_threads()))
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
@@ -86,6 +93,9 @@ def main():
     use_dist = world > 1 or os.environ.get("FCPT_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL group: rehearsal
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
+        # the step's kernels on a side stream: on the null stream they shared a hardware queue with RCCL's
+        # stream, and the CFL kernels queued behind the ghost exchange (fcpt_cfl_begin) could not overlap it
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
     lib = fargocpt_amd.load()
     nr_global = args.nr * world
@@ -207,7 +217,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lib, d, fields, radii, bodies)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     ctx.close()
     if use_dist:

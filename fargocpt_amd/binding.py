@@ -257,6 +257,9 @@ class Context:
     def cfl_device(self, d_dt_local: int):
         self._call("cfl_device", C.c_void_p(int(d_dt_local)))
 
+    def cfl_begin(self):
+        self._call("cfl_begin")
+
     def calculate_timestep_device(self, d_cfl_global: int):
         self._call("calculate_timestep_device", C.c_void_p(int(d_cfl_global)))
 

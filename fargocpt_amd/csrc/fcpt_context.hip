@@ -45,6 +45,8 @@ struct fcpt_ctx {
     double policy_dt_host = -1.0; // the last kick left the energy in energy_b (marching source step, ideal EOS)
     bool march_source = true;
     bool stepped = false; // fcpt_step ran since the last fcpt_post
+    bool cfl_interior = false; // fcpt_cfl_begin evaluated the interior rings of the current state
+    bool damp_any = false;     // this slab holds rings of a damping zone
     bool pressure_valid = false;
     // leapfrog: bodies at the mid-step time (simulation.cpp:359-366)
     bool has_mid = false;
@@ -278,6 +280,7 @@ void enqueue_potential(fcpt_ctx *c, bool midstep)
 // length is already in the device clock (device-resident dt), else `dt` is written there.
 void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe)
 {
+    c->cfl_interior = false;
     const Dev &P = c->P;
     hipStream_t st = c->stream;
     const bool frog = c->d.integrator == FCPT_INTEGRATOR_LEAPFROG;
@@ -775,6 +778,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
             return rc;
         }
         // leapfrog kicks the gas once more after the transport, so its damping cannot be folded in
+        c->damp_any = d->damping && any;
         P.damp_in_step = (d->damping && any && !mean && d->integrator == FCPT_INTEGRATOR_EULER) ? 1 : 0;
         if (const char *e = getenv("FCPT_FUSED_DAMPING"))
             if (e[0] == '0')
@@ -894,6 +898,7 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
     HIPCHK(hipStreamSynchronize(c->stream));
     if (f == FCPT_F_SCALE_HEIGHT)
         c->potential_valid = false;
+    c->cfl_interior = false;
     return FCPT_OK;
 }
 
@@ -1039,12 +1044,43 @@ int fcpt_init_physics(fcpt_ctx *c)
     return FCPT_OK;
 }
 
+} // extern "C"
+namespace {
+void enqueue_cfl(fcpt_ctx *c, int apply_policy)
+{
+    launch_cfl(c->P, apply_policy, c->stream, c->cfl_interior);
+    c->cfl_interior = false;
+}
+} // namespace
+extern "C" {
+
+// condition_cfl for the rings that neither the ghost exchange nor the boundary kernels touch, to be queued between
+// fcpt_exchange_pack and the wait for the neighbours' rings: it runs while they are on the wire.  The next
+// fcpt_cfl / fcpt_cfl_device evaluates the remaining rings and reduces.  A no-op (the whole CFL runs later)
+// whenever that split would not see the final state: damping outside the step kernels, narrow rings, ...
+int fcpt_cfl_begin(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    c->cfl_interior = false;
+    const bool state_final = c->stepped && (!c->damp_any || c->P.damp_in_step != 0); // fcpt_post will not damp
+    if (!state_final)
+        return FCPT_OK;
+    if (const char *e = getenv("FCPT_CFL_SPLIT"))
+        if (e[0] == '0')
+            return FCPT_OK;
+    ProfScope prof_scope(c);
+    c->cfl_interior = launch_cfl_interior(c->P, c->stream);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
 int fcpt_cfl(fcpt_ctx *c, double *dt_local)
 {
     if (!c || !dt_local)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    launch_cfl(c->P, 0, c->stream);
+    enqueue_cfl(c, 0);
     HIPCHK(hipGetLastError());
     DevClock k;
     if (int rc = read_clock(c, &k))
@@ -1060,7 +1096,7 @@ int fcpt_cfl_device(fcpt_ctx *c, double *d_dt_local)
     if (!c || !d_dt_local)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
-    launch_cfl(c->P, 0, c->stream);
+    enqueue_cfl(c, 0);
     launch_clock_export_cfl(c->P.clk, d_dt_local, c->stream);
     HIPCHK(hipGetLastError());
     return FCPT_OK;
@@ -1170,22 +1206,52 @@ int fcpt_exchange_count(const fcpt_ctx *c, uint64_t *count)
     return FCPT_OK;
 }
 
+} // extern "C"
+namespace {
+// device buffers (RCCL sends them in place) go through one copy kernel; host buffers (slabs of one process,
+// staged exchange) through hipMemcpyAsync per field and side
+bool exchange_on_device(const void *p)
+{
+    if (!p)
+        return true;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain host memory: not an error here
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+int exchange_memcpy(fcpt_ctx *c, double *inner, double *outer, int unpack)
+{
+    const Dev &P = c->P;
+    const size_t l = (size_t)FCPT_OVERLAP * P.nphi, lb = l * sizeof(double);
+    const size_t row_in = unpack ? 0 : l, row_out = (size_t)(P.nr - (unpack ? 1 : 2) * FCPT_OVERLAP) * P.nphi;
+    double *field[4] = {P.sigma, P.vrad, P.vazi, P.energy};
+    const int nq = P.adiabatic ? 4 : 3;
+    for (int q = 0; q < nq; ++q) {
+        if (inner)
+            HIPCHK(unpack ? hipMemcpyAsync(field[q] + row_in, inner + q * l, lb, hipMemcpyDefault, c->stream)
+                          : hipMemcpyAsync(inner + q * l, field[q] + row_in, lb, hipMemcpyDefault, c->stream));
+        if (outer)
+            HIPCHK(unpack ? hipMemcpyAsync(field[q] + row_out, outer + q * l, lb, hipMemcpyDefault, c->stream)
+                          : hipMemcpyAsync(outer + q * l, field[q] + row_out, lb, hipMemcpyDefault, c->stream));
+    }
+    return FCPT_OK;
+}
+} // namespace
+extern "C" {
+
 // commbound.cpp:108-125: rows [7,14) -> inner neighbour, rows [nr-14,nr-7) -> outer
 int fcpt_exchange_pack(fcpt_ctx *c, double *send_inner, double *send_outer)
 {
     if (!c)
         return FCPT_EINVAL;
-    const Dev &P = c->P;
-    const size_t l = (size_t)FCPT_OVERLAP * P.nphi, lb = l * sizeof(double);
-    const size_t o = (size_t)(P.nr - 2 * FCPT_OVERLAP) * P.nphi;
-    const double *src[4] = {P.sigma, P.vrad, P.vazi, P.energy};
-    const int nq = P.adiabatic ? 4 : 3;
-    for (int q = 0; q < nq; ++q) {
-        if (send_inner)
-            HIPCHK(hipMemcpyAsync(send_inner + q * l, src[q] + l, lb, hipMemcpyDeviceToDevice, c->stream));
-        if (send_outer)
-            HIPCHK(hipMemcpyAsync(send_outer + q * l, src[q] + o, lb, hipMemcpyDeviceToDevice, c->stream));
-    }
+    if (c->P.nr < 2 * FCPT_OVERLAP)
+        return FCPT_EINVAL;
+    if (!exchange_on_device(send_inner) || !exchange_on_device(send_outer))
+        return exchange_memcpy(c, send_inner, send_outer, 0);
+    if (send_inner || send_outer)
+        launch_exchange_copy(c->P, send_inner, send_outer, 0, c->stream);
     return FCPT_OK;
 }
 
@@ -1194,17 +1260,12 @@ int fcpt_exchange_unpack(fcpt_ctx *c, const double *recv_inner, const double *re
 {
     if (!c)
         return FCPT_EINVAL;
-    const Dev &P = c->P;
-    const size_t l = (size_t)FCPT_OVERLAP * P.nphi, lb = l * sizeof(double);
-    const size_t oo = (size_t)(P.nr - FCPT_OVERLAP) * P.nphi;
-    double *dst[4] = {P.sigma, P.vrad, P.vazi, P.energy};
-    const int nq = P.adiabatic ? 4 : 3;
-    for (int q = 0; q < nq; ++q) {
-        if (recv_inner)
-            HIPCHK(hipMemcpyAsync(dst[q], recv_inner + q * l, lb, hipMemcpyDeviceToDevice, c->stream));
-        if (recv_outer)
-            HIPCHK(hipMemcpyAsync(dst[q] + oo, recv_outer + q * l, lb, hipMemcpyDeviceToDevice, c->stream));
-    }
+    if (c->P.nr < 2 * FCPT_OVERLAP)
+        return FCPT_EINVAL;
+    if (!exchange_on_device(recv_inner) || !exchange_on_device(recv_outer))
+        return exchange_memcpy(c, const_cast<double *>(recv_inner), const_cast<double *>(recv_outer), 1);
+    if (recv_inner || recv_outer)
+        launch_exchange_copy(c->P, const_cast<double *>(recv_inner), const_cast<double *>(recv_outer), 1, c->stream);
     return FCPT_OK;
 }
 
@@ -1259,7 +1320,7 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
     if (!snap) {
         // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
         for (; n < nsteps; ++n) {
-            launch_cfl(c->P, 1, c->stream); // CFL + CalculateTimeStep policy on the device
+            enqueue_cfl(c, 1); // CFL + CalculateTimeStep policy on the device
             enqueue_step(c, true, 0.0, c->d.cfl <= 0.8); // dt: the policy kernel of launch_cfl just above
             enqueue_post(c);
         }

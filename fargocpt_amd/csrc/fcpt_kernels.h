@@ -41,6 +41,7 @@ void launch_stress(const Dev &P, hipStream_t st);
 void launch_viscous_update(const Dev &P, hipStream_t st);
 void launch_substep3(const Dev &P, int update_energy, hipStream_t st);
 void launch_boundary(const Dev &P, hipStream_t st);
+void launch_exchange_copy(const Dev &P, double *inner, double *outer, int unpack, hipStream_t st);
 void launch_damping(const Dev &P, double *q, double *q0, const double *radius, const DampRange &r,
                     int is_density, hipStream_t st);
 // Where Transport() left the new state: the marching kernels cannot work in place (neighbouring
@@ -62,7 +63,8 @@ void launch_substep3_after_fused(const Dev &P, hipStream_t st);
 void launch_derived(const Dev &P, hipStream_t st);
 void launch_pressure(const Dev &P, hipStream_t st);
 void launch_temperature(const Dev &P, hipStream_t st);
-void launch_cfl(const Dev &P, int apply_policy, hipStream_t st);
+void launch_cfl(const Dev &P, int apply_policy, hipStream_t st, bool interior_done = false);
+bool launch_cfl_interior(const Dev &P, hipStream_t st);
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st);
 void launch_clock_scale_dt(DevClock *clk, int mode, double dt, double factor, hipStream_t st);
 void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st);

@@ -242,3 +242,32 @@ __global__ void k_damping(const Dev P, double *q, double *q0, const double *radi
         q[IDX(i, j)] = (X - X0) * exp_factor + X0;
     }
 }
+
+// ---------------------------------------------------------------------------
+// commbound.cpp:108-125|163-180: the 7 overlap rings of Sigma, v_r, v_phi(, e) to / from both neighbours in ONE
+// launch (six to eight hipMemcpyAsync of 7 rings each cost 5 us apiece on the step's critical path).
+// blockIdx.y = 2 * field + side; rings are contiguous, so this is a flat 16-byte copy.  `row0[side]`: first ring
+// of the field's block; pack copies field -> buffer, unpack buffer -> field.
+struct ExchangeArgs {
+    double *field[4];
+    double *buf[2]; // inner, outer (null: no neighbour on that side)
+    int row0[2];
+    int nq, nphi, unpack;
+};
+__global__ void __launch_bounds__(256) k_exchange_copy(const ExchangeArgs a)
+{
+    const int q = blockIdx.y >> 1, side = blockIdx.y & 1;
+    double *buf = a.buf[side];
+    if (!buf)
+        return;
+    const size_t l = (size_t)FCPT_OVERLAP * a.nphi;
+    double *f = a.field[q] + (size_t)a.row0[side] * a.nphi;
+    double *b = buf + (size_t)q * l;
+    const double *src = a.unpack ? b : f;
+    double *dst = a.unpack ? f : b;
+    const size_t npair = l >> 1; // rings of even Nphi; the odd tail below
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += (size_t)gridDim.x * blockDim.x)
+        ST2(dst + 2 * p, LD2(src + 2 * p));
+    if ((l & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        dst[l - 1] = src[l - 1];
+}

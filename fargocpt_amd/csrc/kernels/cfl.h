@@ -91,9 +91,12 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
 // the ring against that mean (:222-330) -- v_phi is read once instead of once by k_ring_mean and
 // once by k_cfl_cells.  One partial maximum per ring.
 #define CFL_MAXP 8
-template <bool ADI> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part)
+// The launch covers rings [r1, r1+n1) and [r2, r2+n2): all of them in one go, or (slabs with neighbours) the
+// interior while the ghost rings are on the wire and the rings next to them after the unpack (fcpt_cfl_begin).
+template <bool ADI> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part, int r1, int n1, int r2)
 {
-    const int i = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
+    const int b = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
+    const int i = b < n1 ? r1 + b : r2 + (b - n1);
     const int nphi = P.nphi, npair = nphi >> 1;
     const int t = threadIdx.x;
     const size_t row = (size_t)i * nphi;

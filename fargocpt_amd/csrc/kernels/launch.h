@@ -205,6 +205,27 @@ void launch_substep3(const Dev &P, int update_energy, hipStream_t st)
         LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
 }
 
+// rows [7,14) and [nr-14,nr-7) -> buffers (unpack = 0), buffers -> rows [0,7) and [nr-7,nr) (unpack = 1)
+void launch_exchange_copy(const Dev &P, double *inner, double *outer, int unpack, hipStream_t st)
+{
+    ExchangeArgs a;
+    a.field[0] = P.sigma;
+    a.field[1] = P.vrad;
+    a.field[2] = P.vazi;
+    a.field[3] = P.energy;
+    a.buf[0] = inner;
+    a.buf[1] = outer;
+    a.row0[0] = unpack ? 0 : FCPT_OVERLAP;
+    a.row0[1] = unpack ? P.nr - FCPT_OVERLAP : P.nr - 2 * FCPT_OVERLAP;
+    a.nq = P.adiabatic ? 4 : 3;
+    a.nphi = P.nphi;
+    a.unpack = unpack;
+    const size_t npair = ((size_t)FCPT_OVERLAP * P.nphi) >> 1;
+    int bx = (int)((npair + 255) / 256);
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    KLAUNCH(KID_BOUNDARY, k_exchange_copy, dim3(bx, 2 * a.nq), dim3(256), a);
+}
+
 void launch_boundary(const Dev &P, hipStream_t st)
 {
     const int bs = 256;
@@ -427,7 +448,11 @@ void launch_disk_on_body(const Dev &P, double x, double y, double r_object, doub
     KLAUNCH(KID_POTENTIAL, k_disk_on_body_final, dim3(1), dim3(256), (const double *)P.cfl_part, (int)(grid.x * grid.y), out);
 }
 
-void launch_cfl(const Dev &P, int apply_policy, hipStream_t st)
+// rings whose CFL terms read nothing the ghost exchange or the boundary kernels write: ring i reads rows i
+// (and i+1 of v_r); fcpt_exchange_unpack writes rows [0,7) and [nr-7,nr)
+#define CFL_EDGE_LO (FCPT_OVERLAP + 1)
+#define CFL_EDGE_HI (FCPT_OVERLAP + 2)
+bool cfl_by_rings(const Dev &P)
 {
     // one block per ring: mean and cells in one pass (even Nphi up to 512 * CFL_MAXP; the isothermal
     // viscosity and sound speed per ring, or the lazily derived ones of the ideal EOS)
@@ -435,11 +460,32 @@ void launch_cfl(const Dev &P, int apply_policy, hipStream_t st)
                  P.stabilize != 2;
     if (const char *e = getenv("FCPT_CFL_RINGS"))
         rings = rings && e[0] != '0';
-    if (rings) {
-        if (P.adiabatic)
-            KLAUNCH(KID_CFL_CELLS, k_cfl_rings<true>, dim3(P.nr), dim3(256), P, P.cfl_part);
+    return rings;
+}
+static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, hipStream_t st)
+{
+    if (n1 + n2 <= 0)
+        return;
+    if (P.adiabatic)
+        KLAUNCH(KID_CFL_CELLS, k_cfl_rings<true>, dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+    else
+        KLAUNCH(KID_CFL_CELLS, k_cfl_rings<false>, dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+}
+// phase 1 of a split CFL: the interior rings only (returns false when the one-block-per-ring kernel does not apply)
+bool launch_cfl_interior(const Dev &P, hipStream_t st)
+{
+    if (!cfl_by_rings(P) || P.nr <= CFL_EDGE_LO + CFL_EDGE_HI)
+        return false;
+    launch_cfl_rings(P, CFL_EDGE_LO, P.nr - CFL_EDGE_LO - CFL_EDGE_HI, 0, 0, st);
+    return true;
+}
+void launch_cfl(const Dev &P, int apply_policy, hipStream_t st, bool interior_done)
+{
+    if (cfl_by_rings(P)) {
+        if (interior_done)
+            launch_cfl_rings(P, 0, CFL_EDGE_LO, P.nr - CFL_EDGE_HI, CFL_EDGE_HI, st);
         else
-            KLAUNCH(KID_CFL_CELLS, k_cfl_rings<false>, dim3(P.nr), dim3(256), P, P.cfl_part);
+            launch_cfl_rings(P, 0, P.nr, 0, 0, st);
         KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
         return;
     }

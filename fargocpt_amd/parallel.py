@@ -32,6 +32,7 @@ class DistributedSlab:
         self.s_in, self.r_in = (mk(), mk()) if self.has_inner else (None, None)
         self.s_out, self.r_out = (mk(), mk()) if self.has_outer else (None, None)
         self._dt = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._cfl_ready = False  # self._dt holds the reduced CFL step of the current state (step_async)
         # gloo has no send/recv of device tensors: GPU slabs on a gloo group (tests: several ranks on
         # the one GPU of a box) stage the ghost rings through host tensors; RCCL sends them in place
         self.stage_host = self.on_gpu and ready and dist.get_backend() == "gloo"
@@ -45,6 +46,7 @@ class DistributedSlab:
 
     # cfl.cpp:379
     def global_cfl(self) -> float:
+        self._cfl_ready = False
         self._dt[0] = self.ctx.cfl()
         if self.world > 1:
             dist.all_reduce(self._dt, op=dist.ReduceOp.MIN)
@@ -54,7 +56,9 @@ class DistributedSlab:
         return self.ctx.calculate_timestep(self.global_cfl())
 
     # commbound.cpp:98-182
-    def exchange(self):
+    def exchange(self, overlap=None):
+        """`overlap`: work queued on the compute stream between posting the transfers and waiting for them
+        (RCCL runs them on its own stream): it must not touch the ghost rings."""
         if self.world == 1:
             return
         self.ctx.exchange_pack(self._arg(self.s_in), self._arg(self.s_out))
@@ -69,7 +73,10 @@ class DistributedSlab:
             ops += [dist.P2POp(dist.isend, s_in, self.rank - 1), dist.P2POp(dist.irecv, r_in, self.rank - 1)]
         if self.has_outer:
             ops += [dist.P2POp(dist.isend, s_out, self.rank + 1), dist.P2POp(dist.irecv, r_out, self.rank + 1)]
-        for w in dist.batch_isend_irecv(ops):
+        works = dist.batch_isend_irecv(ops)
+        if overlap is not None:
+            overlap()
+        for w in works:
             w.wait()
         if self.stage_host:
             if self.has_inner:
@@ -79,17 +86,29 @@ class DistributedSlab:
         self.ctx.exchange_unpack(self._arg(self.r_in), self._arg(self.r_out))
 
     def step_async(self):
-        """One step with dt kept on the device (GPU slabs only): CFL kernels, MIN all-reduce of a
-        one-element device tensor, policy kernel, step, exchange, post -- all enqueued on the
-        current stream, no host synchronisation."""
+        """One step with dt kept on the device (GPU slabs only): policy kernel, step, exchange, post, then the
+        CFL kernels and the MIN all-reduce (cfl.cpp:379) of a one-element device tensor FOR THE NEXT STEP -- all
+        enqueued on the current stream, no host synchronisation.  The CFL reduction over the interior rings is
+        queued while the ghost rings are on the wire (fcpt_cfl_begin).  `invalidate()` after touching the fields
+        by other means."""
         assert self.on_gpu
+        if not self._cfl_ready:
+            self._reduce_cfl()
+        self.ctx.calculate_timestep_device(self._dt.data_ptr())
+        self.ctx.step_device()
+        self.exchange(overlap=self.ctx.cfl_begin)
+        self.ctx.post_device()
+        self._reduce_cfl()
+
+    def _reduce_cfl(self):
         self.ctx.cfl_device(self._dt.data_ptr())
         if self.world > 1:
             dist.all_reduce(self._dt, op=dist.ReduceOp.MIN)
-        self.ctx.calculate_timestep_device(self._dt.data_ptr())
-        self.ctx.step_device()
-        self.exchange()
-        self.ctx.post_device()
+        self._cfl_ready = True
+
+    def invalidate(self):
+        """The reduced CFL step held for the next step_async is stale (fields changed outside step_async)."""
+        self._cfl_ready = False
 
     def prepare(self):
         """main.cpp:117,147 and sim::init (simulation.cpp:462-474)."""

@@ -346,6 +346,14 @@ int fcpt_calculate_timestep_device(fcpt_ctx *ctx, const double *d_cfl_global);
 int fcpt_step_device(fcpt_ctx *ctx);
 int fcpt_post_device(fcpt_ctx *ctx);
 
+/* Hides the ghost exchange behind the next step's CFL reduction (slabs with neighbours): queued after
+ * fcpt_step* and fcpt_exchange_pack, before the caller waits for the neighbours' rings, it evaluates
+ * condition_cfl (src/cfl.cpp:222-330) on the rings that neither fcpt_exchange_unpack nor the boundary kernels
+ * write (rows [8, nr-9)); the next fcpt_cfl / fcpt_cfl_device then only adds the rings next to the ghost zones
+ * and reduces.  Same dt as the unsplit call.  A no-op whenever the interior is not yet final at that point
+ * (damping outside the step kernels, fields uploaded since) -- the later call then does all rings. */
+int fcpt_cfl_begin(fcpt_ctx *ctx);
+
 /* sim::CalculateTimeStep's policy (src/simulation.cpp:100-118) applied to the
  * globally reduced CFL dt: returns min(CFLmaxVar*last_dt, cfl_dt) and stores it
  * as last_dt. */
@@ -372,8 +380,9 @@ int fcpt_step(fcpt_ctx *ctx, double dt);
 /* CommunicateBoundaries, device side (src/commbound.cpp:108-125,163-180):
  * pack rows [7,14) -> send_inner and rows [nr-14,nr-7) -> send_outer of
  * Sigma, vrad, vazi(, energy); unpack recv_inner -> rows [0,7) and
- * recv_outer -> rows [nr-7,nr).  Buffers are device pointers of
- * fcpt_exchange_count() doubles each; a NULL pointer skips that side.  The
+ * recv_outer -> rows [nr-7,nr).  Buffers hold fcpt_exchange_count() doubles
+ * each; device buffers take one copy kernel per call, host buffers one
+ * hipMemcpyAsync per field and side; a NULL pointer skips that side.  The
  * transfer itself (RCCL send/recv between neighbouring slabs) is done by the
  * caller on the same stream. */
 int fcpt_exchange_count(const fcpt_ctx *ctx, uint64_t *count);

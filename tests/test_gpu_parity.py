@@ -391,3 +391,50 @@ def test_stabilize_viscosity(product, oracle, case):
             ctx.download(B.F_VISC_CFAC_R)   # only with StabilizeViscosity
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("adiabatic,rank,nranks", [(False, 1, 3), (True, 1, 3), (False, 0, 2), (True, 1, 2)])
+def test_cfl_split_around_the_ghost_exchange(product, adiabatic, rank, nranks, monkeypatch):
+    """fcpt_cfl_begin (interior rings, queued while the ghost rings travel) + fcpt_cfl (the rest) must give the
+    dt of the unsplit reduction, bit for bit, on slabs with neighbours (middle slab; first and last slab, whose
+    damping zones are handled inside the step kernels) -- and must really split (two launches of the ring
+    kernel instead of one)."""
+    import torch
+    from fargocpt_amd import driver
+    d = setups.planet_disk(product, nranks * 40, 320, adiabatic=adiabatic)
+    d.rank, d.nranks = rank, nranks
+    radii = product.radii(d)
+    fields = product.initial_fields(d.copy(), radii)
+    names = product.kernel_names()
+    got = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("FCPT_CFL_SPLIT", split)
+        ctx = driver.make_context(product, d, fields=fields, radii=radii, bodies=setups.jupiter_bodies(d))
+        cnt = ctx.exchange_count()
+        bufs = [torch.zeros(cnt, dtype=torch.float64, device="cuda") if has else None
+                for has in (rank > 0, rank < nranks - 1)]
+        ptr = lambda b: None if b is None else b.data_ptr()
+        dts, launches = [], 0
+        for _ in range(2):
+            ctx.calculate_timestep(ctx.cfl())
+        for n in range(6):
+            dt = ctx.calculate_timestep(ctx.cfl() if n == 0 else dts[-1])
+            ctx.step(dt)
+            ctx.exchange_pack(ptr(bufs[0]), ptr(bufs[1]))
+            ctx.synchronize()
+            for b in bufs:                  # stand-in for the neighbours: the ghost rows get new values
+                if b is not None:
+                    b.mul_(1.0 + 1.0e-4)
+            torch.cuda.synchronize()
+            ctx.profile_start([names.index("k_cfl_cells")], max_launches=8)
+            ctx.cfl_begin()
+            ctx.exchange_unpack(ptr(bufs[0]), ptr(bufs[1]))
+            ctx.post(dt)
+            dts.append(ctx.cfl())
+            launches += ctx.profile_stop()["k_cfl_cells"][1]
+        got.append((dts, launches, ctx.state()))
+        ctx.close()
+    assert got[0][0] == got[1][0]
+    assert got[0][1] == 12 and got[1][1] == 6
+    for k in ("sigma", "vrad", "vazi"):
+        assert np.array_equal(got[0][2][k], got[1][2][k])
