@@ -90,27 +90,27 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
 // (CFL_MAXP pairs per thread), sums them (<v_phi>, cfl.cpp:196-205), then evaluates the cells of
 // the ring against that mean (:222-330) -- v_phi is read once instead of once by k_ring_mean and
 // once by k_cfl_cells.  One partial maximum per ring.
-#define CFL_MAXP 8
+#define CFL_MAXP 8 // pairs of cells per thread (Nphi <= 4096); 16 for rings up to 8192 cells
 // The launch covers rings [r1, r1+n1) and [r2, r2+n2): all of them in one go, or (slabs with neighbours) the
 // interior while the ghost rings are on the wire and the rings next to them after the unpack (fcpt_cfl_begin).
-template <bool ADI> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part, int r1, int n1, int r2)
+template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part, int r1, int n1, int r2)
 {
     const int b = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
     const int i = b < n1 ? r1 + b : r2 + (b - n1);
     const int nphi = P.nphi, npair = nphi >> 1;
     const int t = threadIdx.x;
     const size_t row = (size_t)i * nphi;
-    D2 va[CFL_MAXP];
+    D2 va[MAXP];
     double acc = 0.0, acc2 = 0.0;
 #pragma unroll
-    for (int n = 0; n < CFL_MAXP; ++n) {
+    for (int n = 0; n < MAXP; ++n) {
         const int p = t + n * 256;
         va[n] = D2{0.0, 0.0};
         if (p < npair)
             va[n] = *(const D2 *)(P.vazi + row + 2 * p);
     }
 #pragma unroll
-    for (int n = 0; n < CFL_MAXP; ++n) {
+    for (int n = 0; n < MAXP; ++n) {
         acc += va[n].x;
         acc2 += va[n].y;
     }
@@ -139,7 +139,7 @@ template <bool ADI> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev
         const double nu_iso = ADI ? 0.0 : (P.alpha_viscosity ? P.nu_ring[i] : P.nu_const);
         const double sub = P.fast_transport ? mean : 0.0;
 #pragma unroll
-        for (int n = 0; n < CFL_MAXP; ++n) {
+        for (int n = 0; n < MAXP; ++n) {
             const int p = t + n * 256;
             if (p < npair) {
                 const int j = 2 * p;

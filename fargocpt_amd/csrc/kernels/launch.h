@@ -454,9 +454,9 @@ void launch_disk_on_body(const Dev &P, double x, double y, double r_object, doub
 #define CFL_EDGE_HI (FCPT_OVERLAP + 2)
 bool cfl_by_rings(const Dev &P)
 {
-    // one block per ring: mean and cells in one pass (even Nphi up to 512 * CFL_MAXP; the isothermal
+    // one block per ring: mean and cells in one pass (even Nphi up to 1024 * CFL_MAXP = 8192; the isothermal
     // viscosity and sound speed per ring, or the lazily derived ones of the ideal EOS)
-    bool rings = (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 512 * CFL_MAXP && (!P.adiabatic || P.lazy_derived) &&
+    bool rings = (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 1024 * CFL_MAXP && (!P.adiabatic || P.lazy_derived) &&
                  P.stabilize != 2;
     if (const char *e = getenv("FCPT_CFL_RINGS"))
         rings = rings && e[0] != '0';
@@ -466,10 +466,15 @@ static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, hipSt
 {
     if (n1 + n2 <= 0)
         return;
-    if (P.adiabatic)
-        KLAUNCH(KID_CFL_CELLS, k_cfl_rings<true>, dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+    const bool wide = P.nphi > 512 * CFL_MAXP;
+    if (P.adiabatic && wide)
+        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<true, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+    else if (P.adiabatic)
+        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<true, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+    else if (wide)
+        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<false, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
     else
-        KLAUNCH(KID_CFL_CELLS, k_cfl_rings<false>, dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<false, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
 }
 // phase 1 of a split CFL: the interior rings only (returns false when the one-block-per-ring kernel does not apply)
 bool launch_cfl_interior(const Dev &P, hipStream_t st)

@@ -438,3 +438,12 @@ def test_cfl_split_around_the_ghost_exchange(product, adiabatic, rank, nranks, m
     assert got[0][1] == 12 and got[1][1] == 6
     for k in ("sigma", "vrad", "vazi"):
         assert np.array_equal(got[0][2][k], got[1][2][k])
+
+
+@pytest.mark.parametrize("adiabatic", [False, True])
+def test_wide_rings_6144(product, oracle, adiabatic):
+    """BASELINE config 4's ring length (Nphi = 6144 > 4096): the one-block-per-ring CFL kernel with 16 cell
+    pairs per thread, the fused transport kernel over 96 column tiles."""
+    d = setups.planet_disk(product, 24, 6144, adiabatic=adiabatic)
+    fields = ("sigma", "vrad", "vazi", "energy") if adiabatic else ("sigma", "vrad", "vazi")
+    _check(run_pair(product, oracle, d, 12, bodies=setups.jupiter_bodies(d)), fields)

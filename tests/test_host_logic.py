@@ -140,7 +140,8 @@ def test_hot_kernel_occupancy_budget():
         "k_transport_fusedILi1ELb1ELb1ELi0E": 3,   # ideal EOS
         "14k_source_marchILi1E": 6,                # isothermal source step, TW artificial viscosity
         "k_source_march_adiILi1ELb0E": 3,          # ideal EOS, no cooling terms compiled in
-        "k_cfl_ringsILb0E": 6,
+        "k_cfl_ringsILb0ELi8E": 6,                 # Nphi <= 4096
+        "k_cfl_ringsILb0ELi16E": 4,                # rings of up to 8192 cells
     }
     for frag, waves in budget.items():
         hits = [k for k in usage if frag in k]
