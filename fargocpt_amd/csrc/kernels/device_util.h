@@ -110,12 +110,23 @@ __device__ __forceinline__ double dmax(double a, double b) { return a < b ? b : 
 // Whole-wavefront shifts by one lane as DPP moves (gfx9 wave_shr:1 / wave_shl:1): the value of
 // lane-1 / lane+1, lanes 0 / 63 keep their own value.  Two VALU moves instead of two
 // ds_bpermute round trips through the LDS crossbar (profiles/tools/dpp_shift.hip).
+// The read-modify-write form costs a register copy per half (90 of the 770 vector instructions per
+// ring of k_transport_fused); the bound_ctrl form without it (FCPT_DPP_BOUND_CTRL: lanes 0 / 63 read 0,
+// parity-clean because those lanes are halo) removes them and measured 2 % SLOWER per step, three
+// A/B pairs in one session: the marching kernels are bound by dependent-issue latency, not by the
+// instruction count.
 template <int CTRL> __device__ __forceinline__ double dpp_shift(double x)
 {
+#ifdef FCPT_DPP_BOUND_CTRL
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+#else
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
+#endif
 }
 __device__ __forceinline__ double lane_prev(double x) { return dpp_shift<0x138>(x); }
 __device__ __forceinline__ double lane_next(double x) { return dpp_shift<0x130>(x); }
