@@ -386,6 +386,12 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         set_error("Opacity: only Lin, Const and Simple are supported");
         return FCPT_EINVAL;
     }
+    // the exponential spacing's Newton iteration (init.cpp:113-131) collapses to NaN for coarse grids
+    for (int i = 0; d->nr_global >= 1 && i <= d->nr_global + FCPT_GEOM_PAD; ++i)
+        if (!std::isfinite(radii[i]) || radii[i] <= 0.0 || (i > 0 && !(radii[i] > radii[i - 1]))) {
+            set_error("radii[%d] = %g: the interfaces must be finite, positive and strictly increasing", i, radii[i]);
+            return FCPT_EINVAL;
+        }
     if ((long long)(d->nr_global + 1) * (long long)d->nphi >= (1ll << 31)) {
         set_error("grid too large for 32-bit cell indices");
         return FCPT_EINVAL;

@@ -567,6 +567,13 @@ int orc_create(const fcpt_desc *d, const double *radii, orc_ctx **out)
     if (d->cooling_surface && d->opacity != FCPT_OPACITY_LIN && d->opacity != FCPT_OPACITY_CONST &&
         d->opacity != FCPT_OPACITY_SIMPLE)
         return FCPT_EINVAL;
+    /* the interfaces must be finite and strictly increasing (the exponential spacing's Newton iteration,
+     * init.cpp:113-131, collapses to NaN for coarse grids) */
+    if (d->nr_global < 1)
+        return FCPT_EINVAL;
+    for (int i = 0; i <= d->nr_global + FCPT_GEOM_PAD; ++i)
+        if (!isfinite(radii[i]) || radii[i] <= 0.0 || (i > 0 && !(radii[i] > radii[i - 1])))
+            return FCPT_EINVAL;
     orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
     if (!c)
         return FCPT_ENOMEM;

@@ -1,0 +1,85 @@
+"""Seeded random walks through the configuration space of the path: every draw is one descriptor (grid, EOS,
+viscosity, artificial viscosity, integrator, limiter, transport, per-variable boundary conditions, damping
+targets, cooling, StabilizeViscosity, slabs, planet) advanced a few steps by the HIP library and by the oracle.
+The hand-written parity tests pin named combinations; this one looks for the combinations nobody named."""
+import numpy as np
+import pytest
+
+from fargocpt_amd import binding as B, setups
+from tests.util import rel_err, run_pair
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+NSEEDS = 160
+
+
+def draw(lib, seed):
+    rng = np.random.default_rng(1000 + seed)
+    pick = lambda *xs: xs[int(rng.integers(len(xs)))]
+    adiabatic = bool(rng.integers(2))
+    d = setups.planet_disk(lib, pick(16, 23, 40, 57, 72), pick(8, 17, 64, 130, 144, 256, 320, 514),
+                           adiabatic=adiabatic)
+    d.radial_spacing = pick(B.SPACING_LOGARITHMIC, B.SPACING_LOGARITHMIC, B.SPACING_ARITHMETIC, B.SPACING_EXPONENTIAL)
+    d.viscous_alpha, d.constant_viscosity = pick((1.0e-3, 0.0), (1.0e-2, 0.0), (0.0, 1.0e-5), (0.0, 1.0e-3), (0.0, 0.0))
+    d.artificial_viscosity = pick(B.ARTVISC_NONE, B.ARTVISC_TW, B.ARTVISC_SN)
+    d.artificial_viscosity_factor = pick(1.41, 2.0)
+    d.artificial_viscosity_dissipation = int(rng.integers(2))
+    d.heating_viscous = int(rng.integers(2))
+    d.integrator = pick(B.INTEGRATOR_EULER, B.INTEGRATOR_LEAPFROG)
+    d.flux_limiter = pick(B.LIMITER_VANLEER, B.LIMITER_VANLEER, B.LIMITER_MC)
+    d.fast_transport = pick(1, 1, 0)
+    d.omega_frame = pick(1.0, 0.0)
+    d.cfl = pick(0.5, 0.4)
+    d.radial_viscosity_factor = pick(1.0, 1.0, 2.0)
+    for s in (0, 1):
+        d.bc_sigma[s] = pick(B.BC_ZEROGRADIENT, B.BC_REFERENCE)
+        d.bc_energy[s] = pick(B.BC_ZEROGRADIENT, B.BC_REFERENCE)
+        d.bc_vrad[s] = pick(B.BC_ZEROGRADIENT, B.BC_REFERENCE, B.BC_REFLECTING, B.BC_OUTFLOW, B.BC_KEPLERIAN)
+        d.bc_vaz[s] = pick(B.BC_ZEROGRADIENT, B.BC_REFERENCE, B.BC_KEPLERIAN, B.BC_ZEROSHEAR)
+    d.damping = int(rng.integers(2))
+    for arr in (d.damp_vrad, d.damp_vaz, d.damp_sigma, d.damp_energy):
+        for s in (0, 1):
+            arr[s] = pick(B.DAMP_NONE, B.DAMP_REFERENCE, B.DAMP_REFERENCE, B.DAMP_ZERO, B.DAMP_MEAN)
+    for s in (0, 1):   # damping Sigma or e towards zero empties the zone within a few steps
+        if d.damp_sigma[s] == B.DAMP_ZERO:
+            d.damp_sigma[s] = B.DAMP_REFERENCE
+        if d.damp_energy[s] == B.DAMP_ZERO:
+            d.damp_energy[s] = B.DAMP_REFERENCE
+    d.stabilize_viscosity = pick(0, 0, 0, 1, 2)
+    if adiabatic:
+        cooling = pick("none", "none", "surface_lin", "surface_const", "beta_zero", "beta_reference", "beta_floor")
+        if cooling.startswith("surface"):
+            d.cooling_surface = 1
+            d.opacity = B.OPACITY_LIN if cooling == "surface_lin" else B.OPACITY_CONST
+            d.kappa_const = 1.0e4
+        elif cooling.startswith("beta"):
+            d.cooling_beta, d.cooling_beta_value = 1, pick(5.0, 20.0)
+            d.cooling_beta_reference = {"beta_zero": B.BETAREF_ZERO, "beta_reference": B.BETAREF_REFERENCE,
+                                        "beta_floor": B.BETAREF_FLOOR}[cooling]
+            d.cooling_beta_ramp_up = pick(0.0, 0.05)
+    nslabs = pick(1, 1, 2, 3)
+    while nslabs > 1 and d.nr_global < 22 * nslabs:
+        nslabs -= 1
+    planet = bool(rng.integers(2))
+    return d, nslabs, planet
+
+
+@pytest.mark.parametrize("seed", range(NSEEDS))
+def test_random_configuration(product, oracle, seed):
+    d, nslabs, planet = draw(product, seed)
+    bodies = setups.jupiter_bodies(d) if planet else None
+    adiabatic = d.eos == B.EOS_IDEAL
+    try:
+        b, dtb = run_pair(oracle, oracle, d, 10, bodies=bodies, nslabs=(1, 0))[0]
+    except B.FcptError as err:   # a draw outside the supported space (e.g. NaN radii of a coarse exponential grid):
+        assert "FCPT_EINVAL" in str(err)          # both libraries must refuse it the same way
+        with pytest.raises(B.FcptError, match="FCPT_EINVAL"):
+            run_pair(product, product, d, 1, bodies=bodies, nslabs=(1, 0))
+        return
+    a, dta = run_pair(product, product, d, 10, bodies=bodies, nslabs=(nslabs, 0))[0]
+    if not all(np.isfinite(b[k]).all() for k in b):
+        pytest.skip("the oracle itself left the finite range: not a usable draw")
+    assert np.allclose(dta, dtb, rtol=1e-9, atol=0), "time-step history differs"
+    for k in ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ()):
+        e = rel_err(a[k], b[k])
+        assert e <= TOL, f"seed {seed}: {k}: {e:.3e}"

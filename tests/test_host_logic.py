@@ -149,3 +149,18 @@ def test_hot_kernel_occupancy_budget():
         u = usage[hits[0]]
         assert u["Occupancy [waves/SIMD]"] >= waves, (frag, u)
         assert u["VGPRs Spill"] == 0 and u["ScratchSize [bytes/lane]"] == 0, (frag, u)
+
+
+def test_nan_radii_of_a_coarse_exponential_grid_are_refused(product, oracle):
+    """The reference's Newton iteration for `RadialSpacing: Exponential` (src/init.cpp:113-131) collapses to the
+    trivial root for coarse grids and fills Radii with NaN; both libraries refuse such a grid at create time
+    (before any device is touched) instead of marching NaNs."""
+    from fargocpt_amd import driver, setups
+    d = setups.planet_disk(product, 16, 64)
+    d.radial_spacing = B.SPACING_EXPONENTIAL
+    radii = product.radii(d)
+    assert not np.isfinite(radii).all()
+    assert np.array_equal(np.isnan(radii), np.isnan(oracle.radii(d)))
+    for lib in (oracle, product):
+        with pytest.raises(B.FcptError, match="FCPT_EINVAL"):
+            driver.make_context(lib, d)
