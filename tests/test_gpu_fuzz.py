@@ -83,3 +83,41 @@ def test_random_configuration(product, oracle, seed):
     for k in ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ()):
         e = rel_err(a[k], b[k])
         assert e <= TOL, f"seed {seed}: {k}: {e:.3e}"
+
+
+def _device_loop(lib, d, bodies, nsteps):
+    from fargocpt_amd import driver
+    dd = d.copy()
+    dd.rank, dd.nranks = 0, 1
+    radii = lib.radii(dd)
+    from tests.util import perturb
+    fields = perturb(lib.initial_fields(dd, radii), dd, 1e-3)
+    ctx = driver.make_context(lib, dd, fields=fields, radii=radii, bodies=bodies)
+    S = driver.SlabSet([ctx])
+    S.prepare()
+    assert ctx.run_steps(nsteps) == nsteps
+    out = S.gather()
+    out["time"] = ctx.clock.time
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("seed", range(0, NSEEDS, 2))
+def test_random_configuration_device_loop(product, oracle, seed):
+    """The same draws through fcpt_run_steps: dt from the CFL kernels to the policy kernel to the step without
+    leaving the device, the transport without its fallback launches (CFL <= 0.8) and with the ring sums the
+    source march leaves behind -- the path bench.py times."""
+    d, _, planet = draw(product, seed)
+    bodies = setups.jupiter_bodies(d) if planet else None
+    try:
+        b = _device_loop(oracle, d, bodies, 12)
+    except B.FcptError as err:
+        assert "FCPT_EINVAL" in str(err)
+        return
+    if not all(np.isfinite(v).all() for v in b.values()):
+        pytest.skip("the oracle itself left the finite range: not a usable draw")
+    a = _device_loop(product, d, bodies, 12)
+    assert abs(a["time"] - b["time"]) <= 1e-9 * abs(b["time"])
+    for k in ("sigma", "vrad", "vazi") + (("energy",) if d.eos == B.EOS_IDEAL else ()):
+        e = rel_err(a[k], b[k])
+        assert e <= TOL, f"seed {seed}: {k}: {e:.3e}"
