@@ -257,6 +257,12 @@ class Context:
     def cfl_device(self, d_dt_local: int):
         self._call("cfl_device", C.c_void_p(int(d_dt_local)))
 
+    def step_device_begin(self):
+        self._call("step_device_begin")
+
+    def step_device_end(self):
+        self._call("step_device_end")
+
     def cfl_begin(self):
         self._call("cfl_begin")
 

@@ -47,6 +47,11 @@ struct fcpt_ctx {
     bool stepped = false; // fcpt_step ran since the last fcpt_post
     bool cfl_interior = false; // fcpt_cfl_begin evaluated the interior rings of the current state
     bool damp_any = false;     // this slab holds rings of a damping zone
+    // fcpt_step_device_begin: the interior chunks of the transport run on `side` while the caller's stream
+    // marches the chunks with the neighbours' ghost rings, packs and sends them
+    hipStream_t side = nullptr;
+    hipEvent_t e_fork = nullptr, e_join = nullptr;
+    bool join_pending = false;
     bool pressure_valid = false;
     // leapfrog: bodies at the mid-step time (simulation.cpp:359-366)
     bool has_mid = false;
@@ -150,6 +155,15 @@ DampRange damp_range(const fcpt_ctx *c, int is_vector, int type, int outer)
     return r;
 }
 
+// the caller's stream waits for the interior transport forked by fcpt_step_device_begin
+void join_side(fcpt_ctx *c)
+{
+    if (c->join_pending) {
+        (void)hipStreamWaitEvent(c->stream, c->e_join, 0);
+        c->join_pending = false;
+    }
+}
+
 // boundary_conditions.cpp:65-114
 void apply_boundary_view(fcpt_ctx *c, const Dev &P, bool final, bool damping_done = false)
 {
@@ -182,6 +196,7 @@ int copy_initial_values(fcpt_ctx *c)
 
 int read_clock(fcpt_ctx *c, DevClock *out)
 {
+    join_side(c);
     HIPCHK(hipMemcpyAsync(c->h_clk, c->P.clk, sizeof(DevClock), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = *c->h_clk;
@@ -278,8 +293,9 @@ void enqueue_potential(fcpt_ctx *c, bool midstep)
 // the gas part of step_Euler up to Transport (simulation.cpp:167-217), or of step_LeapFrog
 // (simulation.cpp:316-393): kick 1/2 (dt/2), drift (dt), kick 2/2 (dt/2).  `dt_dev`: the step
 // length is already in the device clock (device-resident dt), else `dt` is written there.
-void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe)
+void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool split = false)
 {
+    join_side(c);
     c->cfl_interior = false;
     const Dev &P = c->P;
     hipStream_t st = c->stream;
@@ -303,7 +319,18 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe)
     apply_boundary_view(c, Q, false);
     if (frog)
         launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step (saved in cfl_dt)
-    const TransportResult tr = launch_transport(Q, P, shear_safe, st);
+    TransportResult tr;
+    if (split && !frog && transport_can_split(Q, shear_safe) && c->side) {
+        launch_shift_means(Q, st);
+        (void)hipEventRecord(c->e_fork, st);
+        (void)hipStreamWaitEvent(c->side, c->e_fork, 0);
+        (void)launch_transport(Q, P, shear_safe, c->side, TRANSPORT_INTERIOR);
+        (void)hipEventRecord(c->e_join, c->side);
+        tr = launch_transport(Q, P, shear_safe, st, TRANSPORT_EDGES);
+        c->join_pending = true;
+    } else {
+        tr = launch_transport(Q, P, shear_safe, st);
+    }
     if (!tr.marched)
         launch_clock_advance(P.clk, st);
     // the marching transport is out of place: the new state may sit in the scratch twins
@@ -343,6 +370,7 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe)
 
 void enqueue_post(fcpt_ctx *c)
 {
+    join_side(c);
     // the damping of the final boundary call was applied by k_velocities when damp_in_step
     apply_boundary_view(c, c->P, true, c->P.damp_in_step != 0 && c->stepped);
     c->stepped = false;
@@ -826,6 +854,14 @@ int fcpt_destroy(fcpt_ctx *c)
         (void)hipHostFree(c->h_clk);
     for (hipEvent_t e : c->prof.events)
         (void)hipEventDestroy(e);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    if (c->e_fork)
+        (void)hipEventDestroy(c->e_fork);
+    if (c->e_join)
+        (void)hipEventDestroy(c->e_join);
     delete c;
     return FCPT_OK;
 }
@@ -834,6 +870,7 @@ int fcpt_set_stream(fcpt_ctx *c, void *hip_stream)
 {
     if (!c)
         return FCPT_EINVAL;
+    join_side(c);
     c->stream = (hipStream_t)hip_stream;
     return FCPT_OK;
 }
@@ -900,6 +937,7 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
         set_error("bad argument to fcpt_upload");
         return FCPT_EINVAL;
     }
+    join_side(c);
     HIPCHK(hipMemcpyAsync(c->grid[f], host, grid_count(c, f) * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (f == FCPT_F_SCALE_HEIGHT)
@@ -914,6 +952,7 @@ int fcpt_download(fcpt_ctx *c, int32_t f, double *host)
         set_error("bad argument to fcpt_download");
         return FCPT_EINVAL;
     }
+    join_side(c);
     if (f == FCPT_F_PRESSURE || (c->P.adiabatic && (f == FCPT_F_SOUNDSPEED || f == FCPT_F_SCALE_HEIGHT ||
                                                      f == FCPT_F_VISCOSITY || f == FCPT_F_TEMPERATURE)))
         ensure_pressure(c);
@@ -999,6 +1038,7 @@ int fcpt_disk_on_body_accel(fcpt_ctx *c, double x, double y, double r_object, do
 {
     if (!c || !out)
         return FCPT_EINVAL;
+    join_side(c);
     ProfScope prof_scope(c);
     if (smoothing_fixed < 0.0 && c->P.adiabatic && !c->P.lazy_derived)
         ensure_pressure(c); // the scale-height grid
@@ -1054,6 +1094,7 @@ int fcpt_init_physics(fcpt_ctx *c)
 namespace {
 void enqueue_cfl(fcpt_ctx *c, int apply_policy)
 {
+    join_side(c);
     launch_cfl(c->P, apply_policy, c->stream, c->cfl_interior);
     c->cfl_interior = false;
 }
@@ -1068,6 +1109,7 @@ int fcpt_cfl_begin(fcpt_ctx *c)
 {
     if (!c)
         return FCPT_EINVAL;
+    join_side(c);
     c->cfl_interior = false;
     const bool state_final = c->stepped && (!c->damp_any || c->P.damp_in_step != 0); // fcpt_post will not damp
     if (!state_final)
@@ -1130,10 +1172,39 @@ int fcpt_step_device(fcpt_ctx *c)
     return FCPT_OK;
 }
 
+// fcpt_step_device for slabs with neighbours: the chunks of the transport that hold the rings the neighbours are
+// waiting for (rows [7,14), [nr-14,nr-7)) are marched on the caller's stream, all others on an internal stream,
+// so that fcpt_exchange_pack and the transfers queued next run under the interior chunks.  Until
+// fcpt_step_device_end only fcpt_exchange_pack may be called.
+int fcpt_step_device_begin(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    if (!c->side) {
+        HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
+    }
+    ProfScope prof_scope(c);
+    enqueue_step(c, true, 0.0, c->policy_dt_dev && c->d.cfl <= 0.8, true);
+    c->policy_dt_dev = false;
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_step_device_end(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    join_side(c);
+    return FCPT_OK;
+}
+
 int fcpt_post_device(fcpt_ctx *c)
 {
     if (!c)
         return FCPT_EINVAL;
+    join_side(c);
     ProfScope prof_scope(c);
     enqueue_post(c);
     HIPCHK(hipGetLastError());
@@ -1197,6 +1268,7 @@ int fcpt_apply_boundary(fcpt_ctx *c, double dt, int32_t final)
 {
     if (!c)
         return FCPT_EINVAL;
+    join_side(c);
     ProfScope prof_scope(c);
     launch_clock_set_dt(c->P.clk, dt, c->stream);
     apply_boundary(c, final != 0);
@@ -1268,6 +1340,7 @@ int fcpt_exchange_unpack(fcpt_ctx *c, const double *recv_inner, const double *re
         return FCPT_EINVAL;
     if (c->P.nr < 2 * FCPT_OVERLAP)
         return FCPT_EINVAL;
+    join_side(c);
     if (!exchange_on_device(recv_inner) || !exchange_on_device(recv_outer))
         return exchange_memcpy(c, const_cast<double *>(recv_inner), const_cast<double *>(recv_outer), 1);
     if (recv_inner || recv_outer)
@@ -1301,6 +1374,7 @@ int fcpt_profile_stop(fcpt_ctx *c, double *ms_total, int64_t *launches)
     if (!c || !ms_total || !launches)
         return FCPT_EINVAL;
     c->profiling = false;
+    join_side(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int k = 0; k < KID_COUNT; ++k) {
         ms_total[k] = 0.0;

@@ -51,8 +51,12 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
 struct TransportResult {
     int marched;  // > 0: a marching kernel ran (new state complete, clock advanced)
     double *sigma, *energy, *vrad, *vazi;
+    int split;    // only a part of the chunks was marched
 };
-TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st);
+enum { TRANSPORT_ALL = 0, TRANSPORT_EDGES = 1, TRANSPORT_INTERIOR = 2 };
+TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st, int part = TRANSPORT_ALL);
+bool transport_can_split(const Dev &P, bool shear_safe);
+void launch_shift_means(const Dev &P, hipStream_t st);
 void launch_substep3_cooling_only(const Dev &P, hipStream_t st);
 void launch_disk_on_body(const Dev &P, double x, double y, double r_object, double smoothing_fixed, double r_sm, double *out,
                          hipStream_t st);

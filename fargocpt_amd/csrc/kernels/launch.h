@@ -253,7 +253,7 @@ static void launch_radial(const Dev &P, const int *only_if, hipStream_t st)
     else
         KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, grid, l.block, P, only_if, gx, gy);
 }
-static void launch_shift_means(const Dev &P, hipStream_t st)
+void launch_shift_means(const Dev &P, hipStream_t st)
 {
     KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 1,
             P.src_ring_nparts ? (const double *)P.ring_part : (const double *)nullptr, P.src_ring_nparts, P.ring_pstride);
@@ -301,7 +301,24 @@ static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, 
 #undef MARCHC
 #undef MARCHK
 
-TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st)
+// the fused kernel runs, nothing is queued behind it, and there are chunks between the two ends
+bool transport_can_split(const Dev &P, bool shear_safe)
+{
+    if (P.nphi < 256 || !shear_safe)
+        return false;
+    for (const char *name : {"FCPT_TRANSPORT_FUSED", "FCPT_TRANSPORT_ROWS", "FCPT_TRANSPORT_FALLBACK"})
+        if (getenv(name))
+            return false; // tuning runs keep the one-launch form
+    if (const char *e = getenv("FCPT_TRANSPORT_SPLIT"))
+        if (e[0] == '0')
+            return false;
+    const int chunks = (P.nr + TF_ROWS - 1) / TF_ROWS, c_lo = (P.nr - 2 * FCPT_OVERLAP) / TF_ROWS;
+    return c_lo >= 2 && c_lo < chunks;
+}
+// part: TRANSPORT_ALL, or -- for slabs with neighbours, when transport_can_split() -- launch_shift_means, then
+// TRANSPORT_INTERIOR on a side stream and TRANSPORT_EDGES (the chunks holding the rings a neighbour receives, rows
+// [7,14) and [nr-14,nr-7)) on the caller's stream, so that the ghost exchange runs under the interior chunks.
+TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st, int part)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     // Transport, TransportEuler.cpp:112-136
@@ -318,25 +335,33 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
         Wm.energy = W.eA;
         Wm.vrad = P.vrad == W.vrad ? W.vrad_b : W.vrad;
         Wm.vazi = P.vazi == W.vazi ? W.vazi_b : W.vazi;
-        launch_shift_means(P, st);
+        if (part == TRANSPORT_ALL)
+            launch_shift_means(P, st); // else: the caller queued it ahead of both parts
         int rows = TF_ROWS;
         if (const char *e = getenv("FCPT_TRANSPORT_ROWS"))
             rows = atoi(e) > 0 ? atoi(e) : rows;
         const int tstride = 64 * CF - (CF == 2 ? TfHalo<2>::lo + TfHalo<2>::hi : TfHalo<1>::lo + TfHalo<1>::hi);
         const int tiles = (P.nphi + tstride - 1) / tstride;
         const int chunks = (P.nr + rows - 1) / rows;
-        const dim3 grid((chunks * tiles + 3) / 4), block(256);
         // shear_safe: dt comes from the CFL policy with CFL <= 0.8, so |Nshift[i] - Nshift[i-1]| <= 1 is
         // guaranteed (cfl.cpp:207-220) and the two idle fallback launches (5 us) are not queued; a
         // violation would still be detected and reported as FCPT_ESHEAR
         int fallback = shear_safe ? 0 : 1;
         if (const char *e = getenv("FCPT_TRANSPORT_FALLBACK"))
             fallback = e[0] != '0';
+        TfChunks ch = {chunks, chunks, 0, 1};
+        const int c_lo = (P.nr - 2 * FCPT_OVERLAP) / rows; // first chunk of the outer tail
+        if (part == TRANSPORT_EDGES)
+            ch = TfChunks{1 + (chunks - c_lo), 1, c_lo - 1, 1};
+        else if (part == TRANSPORT_INTERIOR)
+            ch = TfChunks{c_lo - 1, 0, 1, 0};
+        res.split = part != TRANSPORT_ALL;
+        const dim3 grid((ch.count * tiles + 3) / 4), block(256);
 #define TFK(CC, AA, DD)                                                                                             \
     if (P.limiter == FCPT_LIMITER_MC)                                                                                \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback); \
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback, ch); \
     else                                                                                                             \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, fallback)
+        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, fallback, ch)
 #define TFC(CC)               \
     if (P.adiabatic) {        \
         if (W.damp_in_step)   \

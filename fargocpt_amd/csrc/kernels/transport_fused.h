@@ -23,6 +23,12 @@
 // Validity in cells of a 64*C segment: right 1 (L+ needs v_phi(j+1)), 4 at either end for the
 // two passes, left 1 for L+(j-1), 1 at either end for the v_r lane shift.
 #define TF_ROWS 24
+// The chunks of one launch: `count` of them, the first `lead` are chunks 0..lead-1 of the grid, the others follow
+// `skip` chunks further up.  All chunks at once: {n, n, 0, 1}.  Slabs with neighbours march the chunks that hold
+// the rings the neighbours are waiting for first (fcpt_step_device_begin): {1 + tail, 1, gap, 1} then {gap, 0, 1, 0}.
+struct TfChunks {
+    int count, lead, skip, advance_clock;
+};
 template <int C> struct TfHalo {
     static constexpr int lo = C == 2 ? 6 : 5; // even for C = 2: a lane's two cells are final together
     static constexpr int hi = 6;
@@ -38,7 +44,8 @@ __device__ __forceinline__ double damp_apply(double X, int type, double ef, cons
 }
 
 template <int C, bool ADI, bool DAMP, int LIM>
-__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int has_fallback)
+__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int has_fallback,
+                                                         const TfChunks ch)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     constexpr int LO = TfHalo<C>::lo, HI = TfHalo<C>::hi;
@@ -46,13 +53,16 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
     constexpr int lim = LIM;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int chunk = wave / tiles;
+    const int chunk_l = wave / tiles; // chunk within this launch
+    if (chunk_l >= ch.count)
+        return;
+    const int chunk = chunk_l < ch.lead ? chunk_l : chunk_l + ch.skip;
     const int r0 = chunk * rows;
     const int nr = P.nr, nphi = P.nphi;
     if (r0 >= nr)
         return;
     const int r1 = r0 + rows < nr ? r0 + rows : nr;
-    if (wave == 0 && lane == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
+    if (ch.advance_clock && wave == 0 && lane == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
         W.clk->time += P.clk->dt;
         W.clk->n_hydro_iter += 1;
     }
@@ -76,7 +86,7 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
             return;
         }
     }
-    const int tile = wave - chunk * tiles;
+    const int tile = wave - chunk_l * tiles;
     const int stride = 64 * C - (LO + HI);
     const int a = tile * stride - LO; // first pre-shift column of the segment
     const double dt = P.clk->dt;

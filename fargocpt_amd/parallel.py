@@ -11,6 +11,8 @@ share torch's current stream), CPU tensors for host libraries.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -36,8 +38,15 @@ class DistributedSlab:
         # gloo has no send/recv of device tensors: GPU slabs on a gloo group (tests: several ranks on
         # the one GPU of a box) stage the ghost rings through host tensors; RCCL sends them in place
         self.stage_host = self.on_gpu and ready and dist.get_backend() == "gloo"
+        self.split_step = False
         if self.on_gpu:
-            ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            ctx.set_stream(stream)
+            # fcpt_step_device_begin/_end (the whole exchange under the interior chunks of the transport) is opt-in:
+            # in the one-GPU rehearsal (profiles/tools/time_dist_host.py) it measured the same 470 us per step as
+            # the plain step with the CFL overlap -- the cost left is stream-synchronisation latency, not transfer
+            # time -- and 543 us on the null stream, where the library's side stream and RCCL's serialise
+            self.split_step = stream != 0 and os.environ.get("FCPT_SPLIT_STEP") == "1"
 
     def _arg(self, t):
         if t is None:
@@ -88,17 +97,30 @@ class DistributedSlab:
     def step_async(self):
         """One step with dt kept on the device (GPU slabs only): policy kernel, step, exchange, post, then the
         CFL kernels and the MIN all-reduce (cfl.cpp:379) of a one-element device tensor FOR THE NEXT STEP -- all
-        enqueued on the current stream, no host synchronisation.  The CFL reduction over the interior rings is
-        queued while the ghost rings are on the wire (fcpt_cfl_begin).  `invalidate()` after touching the fields
+        enqueued on the current stream, no host synchronisation.  The ghost rings travel while the interior
+        chunks of the transport and the CFL reduction over the interior rings run (fcpt_step_device_begin/_end,
+        fcpt_cfl_begin).  `invalidate()` after touching the fields
         by other means."""
         assert self.on_gpu
         if not self._cfl_ready:
             self._reduce_cfl()
         self.ctx.calculate_timestep_device(self._dt.data_ptr())
-        self.ctx.step_device()
-        self.exchange(overlap=self.ctx.cfl_begin)
+        if self.world > 1 and self.split_step:
+            # the chunks holding the neighbours' ghost rings first; the others run on the library's side stream
+            # under the pack kernel and the transfers
+            self.ctx.step_device_begin()
+            self.exchange(overlap=self._finish_step)
+        elif self.world > 1:
+            self.ctx.step_device()
+            self.exchange(overlap=self.ctx.cfl_begin)
+        else:
+            self.ctx.step_device()
         self.ctx.post_device()
         self._reduce_cfl()
+
+    def _finish_step(self):
+        self.ctx.step_device_end()
+        self.ctx.cfl_begin()
 
     def _reduce_cfl(self):
         self.ctx.cfl_device(self._dt.data_ptr())

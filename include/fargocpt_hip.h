@@ -346,6 +346,16 @@ int fcpt_calculate_timestep_device(fcpt_ctx *ctx, const double *d_cfl_global);
 int fcpt_step_device(fcpt_ctx *ctx);
 int fcpt_post_device(fcpt_ctx *ctx);
 
+/* fcpt_step_device for slabs with neighbours, in two halves around the caller's ghost exchange: _begin queues
+ * the source step and marches the chunks of the transport that hold the rings the neighbours are waiting for
+ * (rows [7,14) and [nr-14,nr-7)) on the context's stream and all other chunks on an internal stream; the
+ * caller then queues fcpt_exchange_pack and its transfers, which run under the interior chunks; _end makes the
+ * context's stream wait for them.  Between the two only fcpt_exchange_pack may be called.  Same results as
+ * fcpt_step_device (the chunks are independent); falls back to it (and _end is a no-op) when the one-kernel
+ * transport does not apply: leapfrog, rings shorter than 256 cells, a dt that is not the CFL policy's. */
+int fcpt_step_device_begin(fcpt_ctx *ctx);
+int fcpt_step_device_end(fcpt_ctx *ctx);
+
 /* Hides the ghost exchange behind the next step's CFL reduction (slabs with neighbours): queued after
  * fcpt_step* and fcpt_exchange_pack, before the caller waits for the neighbours' rings, it evaluates
  * condition_cfl (src/cfl.cpp:222-330) on the rings that neither fcpt_exchange_unpack nor the boundary kernels

@@ -447,3 +447,59 @@ def test_wide_rings_6144(product, oracle, adiabatic):
     d = setups.planet_disk(product, 24, 6144, adiabatic=adiabatic)
     fields = ("sigma", "vrad", "vazi", "energy") if adiabatic else ("sigma", "vrad", "vazi")
     _check(run_pair(product, oracle, d, 12, bodies=setups.jupiter_bodies(d)), fields)
+
+
+@pytest.mark.parametrize("adiabatic,rank,nranks", [(False, 1, 3), (True, 1, 3), (False, 0, 2), (False, 1, 2)])
+def test_step_split_around_the_ghost_exchange(product, adiabatic, rank, nranks):
+    """fcpt_step_device_begin / _end: the transport chunks with the neighbours' ghost rings on the caller's
+    stream, the others on the library's side stream under the pack kernel.  Same bits as fcpt_step_device, the
+    packed rings included, and really two launches of the marching kernel per step."""
+    import torch
+    from fargocpt_amd import driver
+    d = setups.planet_disk(product, nranks * 120, 320, adiabatic=adiabatic)
+    d.rank, d.nranks = rank, nranks
+    radii = product.radii(d)
+    fields = product.initial_fields(d.copy(), radii)
+    names = product.kernel_names()
+    got = []
+    for split in (True, False):
+        ctx = driver.make_context(product, d, fields=fields, radii=radii, bodies=setups.jupiter_bodies(d))
+        cnt = ctx.exchange_count()
+        bufs = [torch.zeros(cnt, dtype=torch.float64, device="cuda") if has else None
+                for has in (rank > 0, rank < nranks - 1)]
+        ptr = lambda b: None if b is None else b.data_ptr()
+        dt_dev = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            ctx.calculate_timestep(ctx.cfl())
+        launches, packed = 0, []
+        for n in range(6):
+            ctx.cfl_device(dt_dev.data_ptr())
+            ctx.calculate_timestep_device(dt_dev.data_ptr())
+            ctx.profile_start([names.index("k_transport_fused")], max_launches=8)
+            if split:
+                ctx.step_device_begin()
+                ctx.exchange_pack(ptr(bufs[0]), ptr(bufs[1]))
+                ctx.step_device_end()
+            else:
+                ctx.step_device()
+                ctx.exchange_pack(ptr(bufs[0]), ptr(bufs[1]))
+            launches += ctx.profile_stop()["k_transport_fused"][1]
+            ctx.synchronize()
+            packed.append([None if b is None else b.cpu().numpy().copy() for b in bufs])
+            for b in bufs:                  # stand-in for the neighbours: the ghost rows get new values
+                if b is not None:
+                    b.mul_(1.0 + 1.0e-4)
+            torch.cuda.synchronize()
+            ctx.exchange_unpack(ptr(bufs[0]), ptr(bufs[1]))
+            ctx.post_device()
+        st = ctx.state()
+        st["time"] = ctx.clock.time
+        got.append((st, launches, packed))
+        ctx.close()
+    assert got[0][1] == 12 and got[1][1] == 6
+    assert got[0][0]["time"] == got[1][0]["time"]
+    for k in ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ()):
+        assert np.array_equal(got[0][0][k], got[1][0][k]), k
+    for pa, pb in zip(got[0][2], got[1][2]):
+        for x, y in zip(pa, pb):
+            assert (x is None and y is None) or np.array_equal(x, y)
