@@ -46,6 +46,12 @@ ALGO_DOUBLES = {
     "k_ring_mean": (1, 1),
 }
 STEP_BYTES = (256, 320)
+# share of SURVEY.md 8(d)'s pass model (doubles per cell, isothermal | adiabatic) that a fused kernel stands for
+MODEL_PASSES = {
+    "k_transport_fused": ("B+C+D", (27, 33)),
+    "k_transport_theta_march": ("C+D", (19, 23)),
+    "k_source_march": ("A", (5, 7)),
+}
 
 
 def affinity_threads(cap=16):
@@ -209,6 +215,13 @@ def main():
                          # k_transport_fused moves 48 B per cell instead of the model's 216 B and is bound by
                          # the vector pipeline, not by HBM
                          "valu_busy": valu_busy,
+                         # the same kernel time priced with the contract's pass model instead of the kernel's own
+                         # minimal traffic: what fraction of the HBM peak the unfused passes it replaces would need
+                         "model": ({"passes": MODEL_PASSES[dominant][0],
+                                    "bytes_per_launch": MODEL_PASSES[dominant][1][adi] * 8 * slab_cells,
+                                    "achieved": MODEL_PASSES[dominant][1][adi] * 8 * slab_cells / (dom_ms * 1e-3) / 1e9,
+                                    "frac": MODEL_PASSES[dominant][1][adi] * 8 * slab_cells / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                   if dominant in MODEL_PASSES and dom_ms > 0 else None),
                          "note": ("k_transport_fused does passes B+C+D of SURVEY.md 8(d)'s model (27|33 doubles per cell) "
                                   "with 6|8 doubles of traffic; it is bound by the FP64 vector ALUs (valu_busy), not by HBM: "
                                   "frac is its HBM fraction, step_frac the whole step against the 256|320 B model")
