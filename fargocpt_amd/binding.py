@@ -291,6 +291,9 @@ class Context:
     def post(self, dt: float):
         self._call("post", _f64(dt))
 
+    def recalculate_derived(self):
+        self._call("recalculate_derived")
+
     def apply_boundary(self, dt: float, final: bool):
         self._call("apply_boundary", _f64(dt), _i32(1 if final else 0))
 

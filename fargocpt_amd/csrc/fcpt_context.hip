@@ -1105,6 +1105,25 @@ extern "C" {
 // fcpt_exchange_pack and the wait for the neighbours' rings: it runs while they are on the wire.  The next
 // fcpt_cfl / fcpt_cfl_device evaluates the remaining rings and reduces.  A no-op (the whole CFL runs later)
 // whenever that split would not see the final state: damping outside the step kernels, narrow rings, ...
+int fcpt_recalculate_derived(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    join_side(c);
+    ProfScope prof_scope(c);
+    c->stepped = false;
+    c->cfl_interior = false;
+    c->potential_valid = false;
+    if (c->P.adiabatic && !c->P.lazy_derived) {
+        launch_derived(c->P, c->stream);
+        c->pressure_valid = true;
+    } else {
+        c->pressure_valid = false; // evaluated lazily
+    }
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
 int fcpt_cfl_begin(fcpt_ctx *c)
 {
     if (!c)

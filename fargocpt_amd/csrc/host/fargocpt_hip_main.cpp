@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <sstream>
 #include <string>
@@ -365,6 +366,28 @@ void write_grid(fcpt_ctx *ctx, int field, size_t n, const std::string &path)
     fclose(f);
 }
 
+// t_polargrid::read2D (src/polargrid.cpp:301-353): raw doubles, ring-major
+bool read_grid(fcpt_ctx *ctx, int field, size_t n, const std::string &path, bool required)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) {
+        if (required) {
+            fprintf(stderr, "fargocpt_hip: cannot read %s\n", path.c_str());
+            exit(1);
+        }
+        return false;
+    }
+    std::vector<double> buf(n);
+    const size_t got = fread(buf.data(), sizeof(double), n, f);
+    fclose(f);
+    if (got != n) {
+        fprintf(stderr, "fargocpt_hip: %s holds %zu values, expected %zu (Nrad / Naz changed?)\n", path.c_str(), got, n);
+        exit(1);
+    }
+    CHECK(fcpt_upload(ctx, field, buf.data()));
+    return true;
+}
+
 struct misc_entry { // src/output.h:16-24
     unsigned int timestep;
     unsigned int nTimeStep;
@@ -380,7 +403,7 @@ struct misc_entry { // src/output.h:16-24
 int main(int argc, char **argv)
 {
     bool quiet = false;
-    long max_steps = -1;
+    long max_steps = -1, restart_from = -1;
     std::string mode, cfgpath;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -390,11 +413,14 @@ int main(int argc, char **argv)
             max_steps = atol(argv[++i]);
         else if (mode.empty())
             mode = a;
+        else if (mode == "restart" && restart_from < 0 && !a.empty() && a.find_first_not_of("0123456789") == std::string::npos)
+            restart_from = atol(a.c_str());
         else
             cfgpath = a;
     }
-    if (mode != "start" || cfgpath.empty()) {
-        fprintf(stderr, "usage: fargocpt_hip [-q] [-N steps] start <config.yml>\n");
+    // start_mode.cpp:29-113: start | restart [N] | auto
+    if ((mode != "start" && mode != "restart" && mode != "auto") || cfgpath.empty()) {
+        fprintf(stderr, "usage: fargocpt_hip [-q] [-N steps] start|auto|restart [N] <config.yml>\n");
         return 2;
     }
     Config cfg;
@@ -407,6 +433,33 @@ int main(int argc, char **argv)
     std::string outdir = cfg.str("OutputDir", "output/out");
     if (outdir.back() != '/')
         outdir += "/";
+    // start_mode::configure_start_mode (src/start_mode.cpp:29-113): auto = restart from the last snapshot of
+    // snapshots/list.txt if there is one; restart without a number likewise
+    std::string restart_dir;
+    if (mode == "auto" || mode == "restart") {
+        std::string id = restart_from >= 0 ? std::to_string(restart_from) : "";
+        if (id.empty()) {
+            std::ifstream list(outdir + "snapshots/list.txt");
+            std::string line;
+            while (std::getline(list, line))
+                if (!line.empty())
+                    id = line; // output::get_last_snapshot_id
+        }
+        FILE *mf = id.empty() ? nullptr : fopen((outdir + "snapshots/" + id + "/misc.bin").c_str(), "rb");
+        if (mf) {
+            fclose(mf);
+            restart_dir = outdir + "snapshots/" + id + "/";
+            mode = "restart";
+        } else if (mode == "restart" && restart_from >= 0) {
+            fprintf(stderr, "fargocpt_hip: cannot read %ssnapshots/%s/misc.bin\n", outdir.c_str(), id.c_str());
+            return 1;
+        } else {
+            if (!quiet)
+                printf("No output found, starting fresh simulation\n");
+            mode = "start";
+        }
+    }
+    const bool restarting = mode == "restart";
     // keys the path does not consume are tolerated here (the reference dies on unknown keys)
     if (!quiet)
         for (auto &kv : cfg.kv)
@@ -475,7 +528,7 @@ int main(int argc, char **argv)
     // ---- output files -------------------------------------------------------------------------
     mkdirs(outdir + "snapshots/");
     mkdirs(outdir + "monitor/");
-    {
+    if (!restarting) {
         FILE *f = fopen((outdir + "used_rad.dat").c_str(), "w"); // src/init.cpp:228-246
         for (int n = 0; n <= d.nr_global; ++n)
             fprintf(f, "%.18g\n", radii[n]);
@@ -546,10 +599,22 @@ int main(int argc, char **argv)
         }
         fclose(f);
     }
+    // boundary_conditions::initial_values_needed(): the t = 0 grids are part of the state (damping towards them,
+    // reference boundary conditions)
+    bool needs_reference = d.damping != 0;
+    for (int sd = 0; sd < 2; ++sd)
+        needs_reference = needs_reference || d.bc_sigma[sd] == FCPT_BC_REFERENCE || d.bc_energy[sd] == FCPT_BC_REFERENCE ||
+                          d.bc_vrad[sd] == FCPT_BC_REFERENCE || d.bc_vaz[sd] == FCPT_BC_REFERENCE;
+    std::function<void(unsigned, unsigned, const char *)> write_snapshot_as;
     auto write_snapshot = [&](unsigned nsnap, unsigned nmon) {
+        write_snapshot_as(nsnap, nmon, nullptr);
+        if (nsnap == 0 && needs_reference) // simulation.cpp:41-47: the damping data as a reference
+            write_snapshot_as(nsnap, nmon, "reference");
+    };
+    write_snapshot_as = [&](unsigned nsnap, unsigned nmon, const char *name) {
         fcpt_clock clk;
         CHECK(fcpt_get_clock(ctx, &clk));
-        const std::string dir = outdir + "snapshots/" + std::to_string(nsnap) + "/";
+        const std::string dir = outdir + "snapshots/" + (name ? std::string(name) : std::to_string(nsnap)) + "/";
         mkdirs(dir);
         write_grid(ctx, FCPT_F_SIGMA, ns, dir + "Sigma.dat");
         write_grid(ctx, FCPT_F_VRAD, nv, dir + "vrad.dat");
@@ -557,6 +622,9 @@ int main(int argc, char **argv)
         if (d.eos == FCPT_EOS_IDEAL) {
             write_grid(ctx, FCPT_F_ENERGY, ns, dir + "energy.dat");
             write_grid(ctx, FCPT_F_TEMPERATURE, ns, dir + "Temperature.dat");
+            // the CFL condition of the next step reads Q+ and Q- of the last one (cfl.cpp:303-316): restart.cpp:78-95
+            write_grid(ctx, FCPT_F_QPLUS, ns, dir + "Qplus.dat");
+            write_grid(ctx, FCPT_F_QMINUS, ns, dir + "Qminus.dat");
         }
         misc_entry misc;
         memset(&misc, 0, sizeof(misc));
@@ -572,6 +640,8 @@ int main(int argc, char **argv)
         std::ifstream src(cfgpath, std::ios::binary);
         std::ofstream dst(dir + "config.yml", std::ios::binary);
         dst << src.rdbuf();
+        if (name)
+            return; // write_full_output(data, "reference", false): not registered
         f = fopen((outdir + "snapshots/list.txt").c_str(), "a");
         fprintf(f, "%u\n", nsnap);
         fclose(f);
@@ -593,20 +663,67 @@ int main(int argc, char **argv)
         return dt;
     };
     calc_dt();          // main.cpp:117
-    write_snapshot(0, 0); // main.cpp:150-152
+    unsigned n_monitor = 0;
+    unsigned long n_iter = 0, n_iter_last = 0;
+    double time = 0.0;
+    if (restarting) { // restart_load, src/restart.cpp:18-139
+        misc_entry misc;
+        FILE *mf = fopen((restart_dir + "misc.bin").c_str(), "rb");
+        if (!mf || fread(&misc, sizeof(misc), 1, mf) != 1) {
+            fprintf(stderr, "fargocpt_hip: cannot read %smisc.bin\n", restart_dir.c_str());
+            return 1;
+        }
+        fclose(mf);
+        if (needs_reference) {
+            const std::string ref = outdir + "snapshots/reference/";
+            read_grid(ctx, FCPT_F_SIGMA0, ns, ref + "Sigma.dat", true);
+            read_grid(ctx, FCPT_F_VRAD0, nv, ref + "vrad.dat", true);
+            read_grid(ctx, FCPT_F_VAZI0, ns, ref + "vazi.dat", true);
+            if (d.eos == FCPT_EOS_IDEAL)
+                read_grid(ctx, FCPT_F_ENERGY0, ns, ref + "energy.dat", true);
+        }
+        read_grid(ctx, FCPT_F_SIGMA, ns, restart_dir + "Sigma.dat", true);
+        read_grid(ctx, FCPT_F_VRAD, nv, restart_dir + "vrad.dat", true);
+        read_grid(ctx, FCPT_F_VAZI, ns, restart_dir + "vazi.dat", true);
+        if (d.eos == FCPT_EOS_IDEAL) {
+            read_grid(ctx, FCPT_F_ENERGY, ns, restart_dir + "energy.dat", true);
+            const bool qp = read_grid(ctx, FCPT_F_QPLUS, ns, restart_dir + "Qplus.dat", false);
+            const bool qm = read_grid(ctx, FCPT_F_QMINUS, ns, restart_dir + "Qminus.dat", false);
+            if (!(qp && qm) && !quiet)
+                printf("Cannot read Qplus / Qminus, no bitwise identical restarting possible!\n");
+        }
+        fcpt_clock clk;
+        CHECK(fcpt_get_clock(ctx, &clk));
+        clk.time = misc.time;
+        clk.last_dt = misc.last_dt;
+        clk.n_hydro_iter = misc.N_iter;
+        clk.n_monitor = misc.nTimeStep;
+        clk.n_snapshot = misc.timestep;
+        CHECK(fcpt_set_clock(ctx, &clk));
+        time = misc.time;
+        n_monitor = misc.nTimeStep;
+        n_iter = n_iter_last = misc.N_iter;
+        set_bodies(time);
+        CHECK(fcpt_recalculate_derived(ctx));
+        if (!quiet)
+            printf("Restarting from %s at time %f (snapshot %u, monitor step %u).\n", restart_dir.c_str(), time,
+                   misc.timestep, misc.nTimeStep);
+    } else {
+        write_snapshot(0, 0); // main.cpp:150-152
+    }
     CHECK(fcpt_apply_boundary(ctx, 0.0, 0)); // sim::init
-    calc_dt();
+    if (!restarting)
+        calc_dt();
 
     const double t_final = (double)d.nsnapshots * d.nmonitor * d.monitor_timestep;
-    FILE *tlog = fopen((outdir + "monitor/timestepLogging.dat").c_str(), "w");
-    fprintf(tlog, "#version: 2\n#FargoCPT Time log for the hydro timestep size.\n"
+    FILE *tlog = fopen((outdir + "monitor/timestepLogging.dat").c_str(), restarting ? "a" : "w");
+    if (!restarting)
+        fprintf(tlog, "#version: 2\n#FargoCPT Time log for the hydro timestep size.\n"
                   "#variable: 0  | snapshot number | 1\n#variable: 1  | monitor number | 1\n"
                   "#variable: 2  | hydrostep number | 1\n#variable: 3  | Number of Hydrosteps in last monitor_timestep | 1\n"
                   "#variable: 4  | time | code\n#variable: 5  | walltime | s\n#variable: 6  | walltime per hydrostep | ms\n"
                   "#variable: 7  | mean dt | code\n#variable: 8  | min dt | code\n#variable: 9  | max dt | code\n");
-    unsigned n_monitor = 0;
-    unsigned long n_iter = 0, n_iter_last = 0;
-    double time = 0.0, sum_dt = 0, min_dt = 1e300, max_dt = 0;
+    double sum_dt = 0, min_dt = 1e300, max_dt = 0;
     const auto t_start = std::chrono::steady_clock::now();
     auto t_last = t_start;
     const bool moving = bodies.size() > 1;

@@ -329,6 +329,11 @@ int fcpt_disk_on_body_accel(fcpt_ctx *ctx, double x, double y, double r_object, 
  * (src/init.cpp:337-341). */
 int fcpt_init_physics(fcpt_ctx *ctx);
 
+/* recalculate_derived_disk_quantities (src/SourceEuler.cpp:225-249) after the state grids were replaced from
+ * outside (restart_load, src/restart.cpp:18-139: uploads of Sigma, vrad, vazi, energy, Qplus, Qminus and of the
+ * t = 0 grids into FCPT_F_*0, then this call). */
+int fcpt_recalculate_derived(fcpt_ctx *ctx);
+
 /* ---- the hot path -------------------------------------------------------- */
 
 /* cfl::condition_cfl without the MPI_Allreduce (src/cfl.cpp:185-376): the

@@ -2441,6 +2441,23 @@ int orc_post(orc_ctx *c, double dt)
     return FCPT_OK;
 }
 
+/* SourceEuler.cpp:225-249 recalculate_derived_disk_quantities */
+int orc_recalculate_derived(orc_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    if (c->d.eos == FCPT_EOS_ISOTHERMAL) {
+        compute_pressure(c);
+    } else {
+        compute_temperature(c);
+        compute_sound_speed(c);
+        compute_scale_height(c);
+        compute_pressure(c);
+    }
+    update_viscosity(c);
+    return FCPT_OK;
+}
+
 int orc_apply_boundary(orc_ctx *c, double dt, int32_t final)
 {
     if (!c)

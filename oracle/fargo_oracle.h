@@ -50,6 +50,7 @@ int orc_exchange_pack(orc_ctx *c, double *send_inner, double *send_outer);
 int orc_exchange_unpack(orc_ctx *c, const double *recv_inner, const double *recv_outer);
 int orc_post(orc_ctx *c, double dt);
 int orc_apply_boundary(orc_ctx *c, double dt, int32_t final);
+int orc_recalculate_derived(orc_ctx *c);
 int orc_run_steps(orc_ctx *c, int64_t nsteps, int32_t snap, int64_t *nsteps_done);
 
 /* geometry arrays for tests: which = 0 Rmed, 1 Rinf, 2 Rsup, 3 Surf, 4 InvDiffRmed,

@@ -143,3 +143,108 @@ def test_irradiation_setup_file(tmp_path):
     rc = 2.0 / 3.0 * (ri[1:] ** 3 - ri[:-1] ** 3) / (ri[1:] ** 2 - ri[:-1] ** 2)
     T = np.fromfile(out + "snapshots/10/Temperature.dat").reshape(len(rc), -1).mean(1)
     assert _irradiation_deviation(rc, T) < 0.03
+
+
+DISK_YML = """\
+# a small planet disk for the restart test (own text; keys of the reference's config surface)
+Nrad: 48
+Naz: 320
+Rmin: 0.4
+Rmax: 2.5
+RadialSpacing: Logarithmic
+Sigma0: 200 g/cm2
+SigmaSlope: 0.5
+SigmaFloor: 1e-9
+AspectRatio: 0.05
+FlaringIndex: 0.0
+ViscousAlpha: 1.0e-3
+ArtificialViscosity: TW
+ArtificialViscosityFactor: 1.41
+ArtificialViscosityDissipation: Yes
+EquationOfState: {eos}
+AdiabaticIndex: 1.4
+mu: 2.35
+HeatingViscous: Yes
+SurfaceCooling: {cooling}
+Opacity: Lin
+MinimumTemperature: 3 K
+MaximumTemperature: 1e100 K
+Integrator: {integrator}
+Transport: FARGO
+CFL: 0.5
+FirstDT: 1e-3
+OmegaFrame: 1.0
+ThicknessSmoothing: 0.6
+InnerBoundary: Reflecting
+OuterBoundary: Reflecting
+Damping: Yes
+DampingInnerLimit: 1.1
+DampingOuterLimit: 0.9
+DampingTimeFactor: 0.1
+DampingVRadialInner: Reference
+DampingVRadialOuter: Reference
+DampingVAzimuthalInner: Reference
+DampingVAzimuthalOuter: Reference
+DampingSurfaceDensityInner: Reference
+DampingSurfaceDensityOuter: Reference
+DampingEnergyInner: Reference
+DampingEnergyOuter: Reference
+Nsnapshots: 4
+Nmonitor: 2
+MonitorTimestep: 0.05
+OutputDir: {out}
+nbody:
+- name: Star
+  semi-major axis: 0.0 au
+  mass: 1.0 solMass
+- name: Jupiter
+  semi-major axis: 1.0 au
+  mass: 1.0e-3 solMass
+  cubic smoothing factor: 0.6
+"""
+
+
+@pytest.mark.parametrize("eos,integrator,cooling", [("Isothermal", "Euler", "No"), ("Ideal", "Euler", "thermal"),
+                                                    ("Ideal", "Leapfrog", "No")])
+def test_restart_is_bitwise_identical(tmp_path, eos, integrator, cooling):
+    """`fargocpt_hip restart 2 config.yml` and `auto` (restart_load, src/restart.cpp:18-139; start modes,
+    src/start_mode.cpp:29-113): the run continued from snapshot 2 -- state, Q+ / Q-, the t = 0 grids of
+    snapshots/reference for the damping zones, time, last dt and counters from misc.bin -- writes the same bits
+    into snapshots 3 and 4 as the uninterrupted run."""
+    import shutil
+    out = tmp_path / "full"
+    cfg = tmp_path / "config.yml"
+    cfg.write_text(DISK_YML.format(eos=eos, integrator=integrator, cooling=cooling, out=out))
+    r = subprocess.run([BIN, "-q", "start", str(cfg)], capture_output=True, text=True, timeout=360)
+    assert r.returncode == 0, r.stderr
+    full = str(out) + "/"
+    assert open(full + "snapshots/list.txt").read().split() == ["0", "1", "2", "3", "4"]
+    assert os.path.exists(full + "snapshots/reference/Sigma.dat")
+    fields = ["Sigma", "vrad", "vazi"] + (["energy", "Qplus", "Qminus"] if eos == "Ideal" else [])
+    for mode in ("restart", "auto"):
+        part = tmp_path / mode
+        os.makedirs(part / "snapshots")
+        keep = ["0", "1", "2", "reference"]
+        for k in keep:
+            shutil.copytree(full + "snapshots/" + k, part / "snapshots" / k)
+        (part / "snapshots" / "list.txt").write_text("0\n1\n2\n")
+        cfg2 = tmp_path / f"config_{mode}.yml"
+        cfg2.write_text(DISK_YML.format(eos=eos, integrator=integrator, cooling=cooling, out=part))
+        args = [BIN, "-q", "restart", "2", str(cfg2)] if mode == "restart" else [BIN, "-q", "auto", str(cfg2)]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=360)
+        assert r.returncode == 0, r.stderr
+        assert (part / "snapshots" / "list.txt").read_text().split() == ["0", "1", "2", "3", "4"]
+        for n in ("3", "4"):
+            a, b = _misc(full + f"snapshots/{n}/misc.bin"), _misc(str(part) + f"/snapshots/{n}/misc.bin")
+            assert a == b, (mode, n, a, b)
+            for f in fields:
+                x = np.fromfile(full + f"snapshots/{n}/{f}.dat")
+                y = np.fromfile(str(part) + f"/snapshots/{n}/{f}.dat")
+                assert np.array_equal(x, y), (mode, n, f, np.abs(x - y).max())
+    # `auto` on an empty output directory starts a fresh run
+    fresh = tmp_path / "fresh"
+    cfg3 = tmp_path / "config_fresh.yml"
+    cfg3.write_text(DISK_YML.format(eos=eos, integrator=integrator, cooling=cooling, out=fresh))
+    r = subprocess.run([BIN, "-q", "-N", "3", "auto", str(cfg3)], capture_output=True, text=True, timeout=360)
+    assert r.returncode == 0, r.stderr
+    assert (fresh / "snapshots" / "0" / "Sigma.dat").exists()
