@@ -11,7 +11,7 @@ from typing import Optional
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OVERLAP = 7
 GEOM_PAD = 15
 MAX_BODIES = 8
@@ -77,6 +77,9 @@ class Desc(C.Structure):
         ("cooling_beta", _i32), ("cooling_beta_reference", _i32),
         ("cooling_beta_value", _f64), ("cooling_beta_ramp_up", _f64),
         ("temperature_cgs", _f64), ("density_cgs", _f64), ("opacity_cgs", _f64),
+        ("profile_cutoff_inner", _i32), ("profile_cutoff_outer", _i32),
+        ("profile_cutoff_point_inner", _f64), ("profile_cutoff_width_inner", _f64),
+        ("profile_cutoff_point_outer", _f64), ("profile_cutoff_width_outer", _f64),
     ]
 
     def copy(self) -> "Desc":

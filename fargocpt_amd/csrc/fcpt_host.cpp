@@ -385,6 +385,10 @@ int fcpt_desc_default(fcpt_desc *d)
     d->temperature_cgs = Temp0;
     d->density_cgs = M0 / (L0 * L0 * L0);
     d->opacity_cgs = L0 * L0 / M0;
+    d->profile_cutoff_inner = d->profile_cutoff_outer = 0; // parameters.cpp:762-776
+    d->profile_cutoff_point_inner = 0.0;
+    d->profile_cutoff_point_outer = 1.0e300;
+    d->profile_cutoff_width_inner = d->profile_cutoff_width_outer = 1.0;
     return FCPT_OK;
 }
 
@@ -478,6 +482,21 @@ int fcpt_initial_fields(fcpt_desc *d, const double *Radii, double *sigma, double
                 }
             }
         }
+        // profile cutoffs of Sigma, outer then inner (init.cpp:1063-1146; util.cpp:69-93)
+        auto cut_outer = [&](double r) { return 1.0 / (1.0 + std::exp((r - d->profile_cutoff_point_outer) / d->profile_cutoff_width_outer)); };
+        auto cut_inner = [&](double r) { return 1.0 / (1.0 + std::exp((d->profile_cutoff_point_inner - r) / d->profile_cutoff_width_inner)); };
+        for (int pass = 0; pass < 2; ++pass) {
+            if (!(pass == 0 ? d->profile_cutoff_outer : d->profile_cutoff_inner))
+                continue;
+            for (int i = 0; i < nr; ++i) {
+                const double f = pass == 0 ? cut_outer(Rmed[i]) : cut_inner(Rmed[i]);
+                const double floor = d->sigma_floor * d->sigma0;
+                for (int j = 0; j < nphi; ++j) {
+                    const double v = sigma[at(i, j)] * f;
+                    sigma[at(i, j)] = v > floor ? v : floor;
+                }
+            }
+        }
         if (adi) {
             for (int i = 0; i < nr; ++i)
                 for (int j = 0; j < nphi; ++j) {
@@ -486,6 +505,20 @@ int fcpt_initial_fields(fcpt_desc *d, const double *Radii, double *sigma, double
                                            (d->adiabatic_index - 1.0);
                     energy[at(i, j)] = e > e_floor ? e : e_floor;
                 }
+            // the same cutoffs on the energy (init.cpp:1363-1450)
+            for (int pass = 0; pass < 2; ++pass) {
+                if (!(pass == 0 ? d->profile_cutoff_outer : d->profile_cutoff_inner))
+                    continue;
+                for (int i = 0; i < nr; ++i) {
+                    const double f = pass == 0 ? cut_outer(Rmed[i]) : cut_inner(Rmed[i]);
+                    for (int j = 0; j < nphi; ++j) {
+                        const double v = energy[at(i, j)] * f;
+                        const double e_floor = d->minimum_temperature * sigma[at(i, j)] / d->mu * d->Rgas /
+                                               (d->adiabatic_index - 1.0);
+                        energy[at(i, j)] = v > e_floor ? v : e_floor;
+                    }
+                }
+            }
         }
         if (d->set_sigma0) {
             // gas_total_mass (quantities.cpp:50-73) over this slab's active rings; exact

@@ -320,6 +320,12 @@ void config_to_desc(const Config &c, fcpt_desc &d)
         d.damp_sigma[s] = damp_of(c.str(std::string("DampingSurfaceDensity") + side[s], "None"));
         d.damp_energy[s] = damp_of(c.str(std::string("DampingEnergy") + side[s], "None"));
     }
+    d.profile_cutoff_outer = c.flag("ProfileCutoffOuter", false) ? 1 : 0; // parameters.cpp:762-776
+    d.profile_cutoff_point_outer = num(c, "ProfileCutoffPointOuter", 1.0e300, K_LEN);
+    d.profile_cutoff_width_outer = num(c, "ProfileCutoffWidthOuter", 1.0, K_LEN);
+    d.profile_cutoff_inner = c.flag("ProfileCutoffInner", false) ? 1 : 0;
+    d.profile_cutoff_point_inner = num(c, "ProfileCutoffPointInner", 0.0, K_LEN);
+    d.profile_cutoff_width_inner = num(c, "ProfileCutoffWidthInner", 1.0, K_LEN);
     d.damping = c.flag("Damping", false);
     d.damping_inner_limit = num(c, "DampingInnerLimit", 1.05);
     d.damping_outer_limit = num(c, "DampingOuterLimit", 0.95);

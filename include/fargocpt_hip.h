@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FCPT_ABI_VERSION 2
+#define FCPT_ABI_VERSION 3
 
 /* error codes */
 #define FCPT_OK 0
@@ -207,6 +207,14 @@ typedef struct fcpt_desc {
     double temperature_cgs; /* K per code temperature unit */
     double density_cgs;     /* g/cm^3 per code volume-density unit */
     double opacity_cgs;     /* cm^2/g per code opacity unit */
+    /* initial profiles: Sigma and e times 1 / (1 + exp(+-(r - point) / width)) (src/init.cpp:1063-1146,1363-1450,
+     * src/util.cpp:69-93), floors re-applied */
+    int32_t profile_cutoff_inner;       /* ProfileCutoffInner */
+    int32_t profile_cutoff_outer;       /* ProfileCutoffOuter */
+    double profile_cutoff_point_inner;  /* ProfileCutoffPointInner */
+    double profile_cutoff_width_inner;  /* ProfileCutoffWidthInner */
+    double profile_cutoff_point_outer;  /* ProfileCutoffPointOuter */
+    double profile_cutoff_width_outer;  /* ProfileCutoffWidthOuter */
 } fcpt_desc;
 
 /* Row ranges of a slab, exactly the integers of src/split.cpp:56-78. */

@@ -486,6 +486,28 @@ int orc_initial_fields(fcpt_desc *d, const double *Radii, double *sigma, double 
                         energy[(size_t)i * nphi + j] = 0.0;
                 }
         }
+        /* init.cpp:1063-1104 profile cutoff at the outer boundary, util.cpp:69-81 cutoff_outer */
+        if (d->profile_cutoff_outer)
+            for (int n_radial = 0; n_radial < nr; ++n_radial)
+                for (int n_azimuthal = 0; n_azimuthal < nphi; ++n_azimuthal) {
+                    const double r = Rmed[n_radial];
+                    const double density_damped =
+                        sigma[(size_t)n_radial * nphi + n_azimuthal] *
+                        (1.0 / (1.0 + exp((r - d->profile_cutoff_point_outer) / d->profile_cutoff_width_outer)));
+                    const double density_floor = d->sigma_floor * d->sigma0;
+                    sigma[(size_t)n_radial * nphi + n_azimuthal] = fmax(density_damped, density_floor);
+                }
+        /* init.cpp:1106-1146 profile cutoff at the inner boundary, util.cpp:90-93 cutoff_inner */
+        if (d->profile_cutoff_inner)
+            for (int n_radial = 0; n_radial < nr; ++n_radial)
+                for (int n_azimuthal = 0; n_azimuthal < nphi; ++n_azimuthal) {
+                    const double r = Rmed[n_radial];
+                    const double density_damped =
+                        sigma[(size_t)n_radial * nphi + n_azimuthal] *
+                        (1.0 / (1.0 + exp((d->profile_cutoff_point_inner - r) / d->profile_cutoff_width_inner)));
+                    const double density_floor = d->sigma_floor * d->sigma0;
+                    sigma[(size_t)n_radial * nphi + n_azimuthal] = fmax(density_damped, density_floor);
+                }
         /* init.cpp:1257-1300 (profile); the spreading ring keeps energy = 0 only when
          * isothermal -- init_gas_energy runs after init_gas_density when Adiabatic */
         if (adi) {
@@ -496,6 +518,23 @@ int orc_initial_fields(fcpt_desc *d, const double *Radii, double *sigma, double 
                                            d->mu * d->Rgas / (d->adiabatic_index - 1.0);
                     energy[(size_t)i * nphi + j] = e > e_floor ? e : e_floor;
                 }
+            /* init.cpp:1363-1450 the same cutoffs on the energy */
+            for (int outer = 1; outer >= 0; --outer) {
+                if (!(outer ? d->profile_cutoff_outer : d->profile_cutoff_inner))
+                    continue;
+                for (int n_radial = 0; n_radial < nr; ++n_radial)
+                    for (int n_azimuthal = 0; n_azimuthal < nphi; ++n_azimuthal) {
+                        const double r = Rmed[n_radial];
+                        const double cut =
+                            outer ? 1.0 / (1.0 + exp((r - d->profile_cutoff_point_outer) / d->profile_cutoff_width_outer))
+                                  : 1.0 / (1.0 + exp((d->profile_cutoff_point_inner - r) / d->profile_cutoff_width_inner));
+                        const double energy_damped = energy[(size_t)n_radial * nphi + n_azimuthal] * cut;
+                        const double energy_floor = d->minimum_temperature *
+                                                    sigma[(size_t)n_radial * nphi + n_azimuthal] / d->mu * d->Rgas /
+                                                    (d->adiabatic_index - 1.0);
+                        energy[(size_t)n_radial * nphi + n_azimuthal] = fmax(energy_damped, energy_floor);
+                    }
+            }
         }
         /* init.cpp:1150-1185 renormalize_sigma_and_report; gas_total_mass
          * (quantities.cpp:50-73) over this slab's active rings only -- exact for

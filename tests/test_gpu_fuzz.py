@@ -57,6 +57,10 @@ def draw(lib, seed):
             d.cooling_beta_reference = {"beta_zero": B.BETAREF_ZERO, "beta_reference": B.BETAREF_REFERENCE,
                                         "beta_floor": B.BETAREF_FLOOR}[cooling]
             d.cooling_beta_ramp_up = pick(0.0, 0.05)
+    if rng.integers(4) == 0:    # ProfileCutoffOuter / Inner: the disk ends inside the grid
+        d.profile_cutoff_outer, d.profile_cutoff_point_outer, d.profile_cutoff_width_outer = 1, pick(1.6, 2.0), pick(0.1, 0.2)
+        if rng.integers(2):
+            d.profile_cutoff_inner, d.profile_cutoff_point_inner, d.profile_cutoff_width_inner = 1, 0.6, pick(0.05, 0.1)
     nslabs = pick(1, 1, 2, 3)
     while nslabs > 1 and d.nr_global < 22 * nslabs:
         nslabs -= 1

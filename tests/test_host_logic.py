@@ -87,12 +87,22 @@ def test_radii(product, oracle, spacing):
     assert np.all(np.diff(r) > 0)
 
 
-@pytest.mark.parametrize("name", ["planet_iso", "planet_adi", "ring", "shock"])
+def _cutoff_disk(product, adiabatic):
+    d = setups.planet_disk(product, 48, 16, adiabatic=adiabatic)
+    d.profile_cutoff_outer, d.profile_cutoff_point_outer, d.profile_cutoff_width_outer = 1, 1.8, 0.1
+    d.profile_cutoff_inner, d.profile_cutoff_point_inner, d.profile_cutoff_width_inner = 1, 0.6, 0.05
+    d.set_sigma0, d.disk_mass = 1, 0.01
+    return d
+
+
+@pytest.mark.parametrize("name", ["planet_iso", "planet_adi", "ring", "shock", "cutoff_iso", "cutoff_adi"])
 def test_initial_fields_match_oracle(product, oracle, name):
     d = {"planet_iso": lambda: setups.planet_disk(product, 48, 16),
          "planet_adi": lambda: setups.planet_disk(product, 48, 16, adiabatic=True),
          "ring": lambda: setups.spreading_ring(product, 64, 4),
-         "shock": lambda: setups.shocktube(product, 64, 4)}[name]()
+         "shock": lambda: setups.shocktube(product, 64, 4),
+         "cutoff_iso": lambda: _cutoff_disk(product, False),
+         "cutoff_adi": lambda: _cutoff_disk(product, True)}[name]()
     radii = product.radii(d)
     d1, d2 = d.copy(), d.copy()
     f1, f2 = product.initial_fields(d1, radii), oracle.initial_fields(d2, radii)
@@ -104,6 +114,20 @@ def test_initial_fields_match_oracle(product, oracle, name):
         assert set(np.unique(f1[0])) == {0.125, 1.0}
     if name == "ring":
         assert abs(d1.sigma0 / d.sigma0 - 1) < 0.05  # SetSigma0 renormalisation (init.cpp:1150-1185)
+    if name.startswith("cutoff"):
+        # ProfileCutoffInner / Outer (init.cpp:1063-1146, util.cpp:69-93): the power law times two logistic edges,
+        # then SetSigma0 scales the cut profile to the disk mass
+        ri = np.asarray(radii[:d.nr_global + 1])
+        rm = 2.0 / 3.0 * (ri[1:] ** 3 - ri[:-1] ** 3) / (ri[1:] ** 2 - ri[:-1] ** 2)
+        shape = rm ** -0.5 / (1 + np.exp((rm - 1.8) / 0.1)) / (1 + np.exp((0.6 - rm) / 0.05))
+        sig = f1[0][:, 0]
+        np.testing.assert_allclose(sig / sig[24], shape / shape[24], rtol=1e-12)
+        surf = np.pi * (ri[1:] ** 2 - ri[:-1] ** 2)
+        assert np.sum(surf[1:-1] * sig[1:-1]) == pytest.approx(0.01, rel=1e-12)
+        if name == "cutoff_adi":    # e = Sigma0 h^2 r^(-SigmaSlope - 1 + 2 FlaringIndex) / (gamma - 1) times the same edges
+            e = f1[3][:, 0]
+            eshape = shape / rm
+            np.testing.assert_allclose(e / e[24], eshape / eshape[24], rtol=1e-12)
 
 
 def test_kernel_name_table(product):
