@@ -492,6 +492,31 @@ int main(int argc, char **argv)
     const size_t ns = (size_t)d.nr_global * d.nphi, nv = (size_t)(d.nr_global + 1) * d.nphi;
     std::vector<double> sigma(ns), vrad(nv), vazi(ns), energy(ns);
     CHECK(fcpt_initial_fields(&d, radii.data(), sigma.data(), vrad.data(), vazi.data(), energy.data()));
+    // SigmaCondition / EnergyCondition: 2D (init.cpp:1002-1007,1307-1312: read2D of the named file); 1D needs the
+    // reference's GSL spline and is not offered
+    for (int q = 0; q < 2; ++q) {
+        const std::string cond = lower(cfg.str(q == 0 ? "SigmaCondition" : "EnergyCondition", "profile"));
+        const std::string fn = cfg.str(q == 0 ? "SigmaFilename" : "EnergyFilename", "");
+        if (cond == "profile" || cond.empty())
+            continue;
+        if (cond != "2d" || (q == 1 && d.eos != FCPT_EOS_IDEAL)) {
+            if (q == 1 && cond == "2d")
+                continue; // no energy equation
+            fprintf(stderr, "fargocpt_hip: %sCondition: %s is not supported (Profile, 2D)\n", q == 0 ? "Sigma" : "Energy", cond.c_str());
+            return 2;
+        }
+        if (d.set_sigma0 || d.profile_cutoff_inner || d.profile_cutoff_outer) {
+            fprintf(stderr, "fargocpt_hip: %sCondition: 2D together with SetSigma0 or ProfileCutoff* is not supported\n", q == 0 ? "Sigma" : "Energy");
+            return 2;
+        }
+        std::vector<double> &dst = q == 0 ? sigma : energy;
+        FILE *f = fopen(fn.c_str(), "rb");
+        if (!f || fread(dst.data(), sizeof(double), ns, f) != ns) {
+            fprintf(stderr, "fargocpt_hip: cannot read %zu values from '%s'\n", ns, fn.c_str());
+            return 1;
+        }
+        fclose(f);
+    }
     fcpt_ctx *ctx = nullptr;
     CHECK(fcpt_create(&d, radii.data(), &ctx));
     CHECK(fcpt_upload(ctx, FCPT_F_SIGMA, sigma.data()));

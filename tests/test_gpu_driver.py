@@ -248,3 +248,30 @@ def test_restart_is_bitwise_identical(tmp_path, eos, integrator, cooling):
     r = subprocess.run([BIN, "-q", "-N", "3", "auto", str(cfg3)], capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stderr
     assert (fresh / "snapshots" / "0" / "Sigma.dat").exists()
+
+
+def test_initial_state_from_2d_files(tmp_path):
+    """SigmaCondition / EnergyCondition: 2D (init.cpp:1002-1007, 1307-1312): the grids of a snapshot as the
+    initial state of a new run."""
+    out = tmp_path / "a"
+    cfg = tmp_path / "a.yml"
+    cfg.write_text(DISK_YML.format(eos="Ideal", integrator="Euler", cooling="No", out=out))
+    r = subprocess.run([BIN, "-q", "-N", "40", "start", str(cfg)], capture_output=True, text=True, timeout=360)
+    assert r.returncode == 0, r.stderr
+    sig = np.fromfile(str(out) + "/snapshots/0/Sigma.dat") * 1.25
+    en = np.fromfile(str(out) + "/snapshots/0/energy.dat") * 0.5
+    sig.tofile(tmp_path / "sigma_in.dat")
+    en.tofile(tmp_path / "energy_in.dat")
+    out2 = tmp_path / "b"
+    cfg2 = tmp_path / "b.yml"
+    cfg2.write_text(DISK_YML.format(eos="Ideal", integrator="Euler", cooling="No", out=out2) +
+                    f"SigmaCondition: 2D\nSigmaFilename: {tmp_path / 'sigma_in.dat'}\n"
+                    f"EnergyCondition: 2D\nEnergyFilename: {tmp_path / 'energy_in.dat'}\n")
+    r = subprocess.run([BIN, "-q", "-N", "5", "start", str(cfg2)], capture_output=True, text=True, timeout=360)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(str(out2) + "/snapshots/0/Sigma.dat"), sig)
+    assert np.array_equal(np.fromfile(str(out2) + "/snapshots/0/energy.dat"), en)
+    cfg3 = tmp_path / "c.yml"
+    cfg3.write_text(DISK_YML.format(eos="Ideal", integrator="Euler", cooling="No", out=tmp_path / "c") + "SigmaCondition: 1D\n")
+    r = subprocess.run([BIN, "-q", "start", str(cfg3)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "not supported" in r.stderr
