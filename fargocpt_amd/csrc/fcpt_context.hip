@@ -1073,6 +1073,10 @@ int fcpt_init_physics(fcpt_ctx *c)
     const size_t ns = (size_t)P.nr * P.nphi * sizeof(double);
     HIPCHK(hipMemsetAsync(P.qplus, 0, ns, st));
     HIPCHK(hipMemsetAsync(P.qminus, 0, ns, st));
+    // ... and its compute_viscous_stress_tensor leaves the StabilizeViscosity factors (functions of nu and Sigma
+    // only) behind: with StabilizeViscosity 2 they limit the very first time step (cfl.cpp:331-351)
+    if (P.adiabatic)
+        launch_visc_factors(P, st);
     if (P.adiabatic && (P.cooling_surface || P.cooling_beta || P.heating_star)) {
         // ... but Q- does not vanish: calculate_qminus + the 1/alpha of compute_heating_cooling_for_CFL
         Dev I = P;

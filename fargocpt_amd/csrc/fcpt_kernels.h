@@ -38,6 +38,7 @@ void launch_recalculate_viscosity(const Dev &P, hipStream_t st);
 void launch_viscosity_field(const Dev &P, hipStream_t st);
 void launch_iso_cs_h(const Dev &P, const double *cs_ring, hipStream_t st);
 void launch_stress(const Dev &P, hipStream_t st);
+void launch_visc_factors(const Dev &P, hipStream_t st);
 void launch_viscous_update(const Dev &P, hipStream_t st);
 void launch_substep3(const Dev &P, int update_energy, hipStream_t st);
 void launch_boundary(const Dev &P, hipStream_t st);

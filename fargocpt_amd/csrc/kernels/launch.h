@@ -173,12 +173,17 @@ void launch_substep3_after_fused(const Dev &P, hipStream_t st)
     LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
 }
 
+// viscosity.cpp:256-348: the correction factors depend on nu and Sigma only
+void launch_visc_factors(const Dev &P, hipStream_t st)
+{
+    if (P.stabilize)
+        LAUNCH2D(KID_STRESS_RPHI, k_visc_factors, P.nr - 1, P);
+}
 void launch_stress(const Dev &P, hipStream_t st)
 {
     LAUNCH2D(KID_STRESS_DIAG, k_stress_diag, P.nr, P);
     LAUNCH2D(KID_STRESS_RPHI, k_stress_rphi, P.nr - 1, P);
-    if (P.stabilize)
-        LAUNCH2D(KID_STRESS_RPHI, k_visc_factors, P.nr - 1, P);
+    launch_visc_factors(P, st);
 }
 
 void launch_viscous_update(const Dev &P, hipStream_t st)
