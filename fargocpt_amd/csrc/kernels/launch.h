@@ -418,7 +418,14 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
     if (const char *e = getenv("FCPT_THETA_MARCH"))
         march = march && e[0] != '0';
     if (march) {
-        res.marched = launch_theta_march(P, W, C, periodic, 1, nullptr, st);
+        // the kernel reads the pre-transport v_phi and v_r of a ring (halo columns included) while other
+        // wavefronts already store the new ones: never in place (the per-loop source step leaves its result in
+        // the state grids themselves, the marching one in the *_b twins)
+        Dev Wm = W;
+        Wm.vrad = P.vrad == W.vrad ? W.vrad_b : W.vrad;
+        Wm.vazi = P.vazi == W.vazi ? W.vazi_b : W.vazi;
+        res.marched = launch_theta_march(P, Wm, C, periodic, 1, nullptr, st);
+        res.vrad = Wm.vrad, res.vazi = Wm.vazi;
     } else if (C) {
         const int tstride = 64 * C - 2 * THETA_HALO;
         const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;

@@ -28,7 +28,7 @@ def perturb(fields, d, amp=1e-3):
     return sigma, vrad, vazi, energy
 
 
-def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=(1, 1), dt_scale=1.0):
+def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=(1, 1), dt_scale=1.0, noise=0.0):
     """Advance the same initial state `nsteps` with two libraries; returns the two global
     states and the two dt histories."""
     outs = []
@@ -39,6 +39,9 @@ def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=
     fields = lib_a.initial_fields(d0, radii)   # d0.sigma0 possibly rescaled
     if amp:
         fields = perturb(fields, d0, amp)
+    if noise:   # cell-wise relative noise (seeded): how fast does this flow amplify rounding-sized differences?
+        rng = np.random.default_rng(7)
+        fields = tuple(f * (1.0 + noise * rng.standard_normal(f.shape)) for f in fields)
     for L, ns in zip((lib_a, lib_b), nslabs):
         if ns == 0:   # only one library wanted
             outs.append(None)
