@@ -83,7 +83,7 @@ def _tolerance(oracle_run, b, fields, worst):
     noise = 1.0e-15
     b2 = oracle_run(noise)
     growth = max(rel_err(b2[k], b[k]) for k in fields) / noise
-    return max(TOL, 3.0e-15 * growth), growth
+    return max(TOL, 3.0e-14 * growth), growth   # the two paths differ by up to ~3e-14 before any amplification
 
 
 @pytest.mark.parametrize("seed", range(FIRST, FIRST + NSEEDS))
