@@ -512,3 +512,59 @@ def test_step_split_around_the_ghost_exchange(product, adiabatic, rank, nranks):
     for pa, pb in zip(got[0][2], got[1][2]):
         for x, y in zip(pa, pb):
             assert (x is None and y is None) or np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("adiabatic,leapfrog,nphi", [(False, False, 320), (False, True, 320), (True, True, 288), (True, False, 96)])
+def test_moving_bodies_indirect_term_and_midstep_positions(product, oracle, adiabatic, leapfrog, nphi):
+    """What the host loop does around every step when the frame does not corotate: fcpt_set_bodies with the
+    bodies' new positions, cubic smoothing radii and the indirect term (Pframeforce.cpp:21-189), for leapfrog
+    also fcpt_set_bodies_midstep with the positions at t + dt/2 (simulation.cpp:359-366).  Two planets on
+    circular orbits, OmegaFrame = 0."""
+    from fargocpt_amd import driver
+    d = setups.planet_disk(product, 56, nphi, adiabatic=adiabatic)
+    d.omega_frame = 0.0
+    if leapfrog:
+        d.integrator = B.INTEGRATOR_LEAPFROG
+    m_star, planets = d.hydro_center_mass, [(1.0, 1.0e-3, 0.0), (1.6, 3.0e-4, 2.0)]   # (a, mass, phase)
+
+    def bodies_at(t):
+        x, y, m, rsm = [0.0], [0.0], [m_star], [0.0]
+        ix = iy = 0.0
+        for a, mp, ph in planets:
+            ang = ph + t * np.sqrt((m_star + mp) / a ** 3)
+            x.append(a * np.cos(ang)), y.append(a * np.sin(ang)), m.append(mp)
+            rsm.append(0.6 * a * np.cbrt(mp / (3.0 * m_star)))
+            ix -= mp * x[-1] / a ** 3     # acceleration of the star by the planet, as the indirect term
+            iy -= mp * y[-1] / a ** 3
+        return (x, y, m, rsm), (ix, iy)
+
+    outs = []
+    for L in (product, oracle):
+        dd = d.copy()
+        dd.rank, dd.nranks = 0, 1
+        radii = L.radii(dd)
+        from tests.util import perturb
+        fields = perturb(L.initial_fields(dd, radii), dd, 1e-3)
+        (x, y, m, rsm), ind = bodies_at(0.0)
+        ctx = driver.make_context(L, dd, fields=fields, radii=radii, bodies=(x, y, m))
+        ctx.set_bodies(x, y, m, rsm, ind)
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        t, dts = 0.0, []
+        for _ in range(14):
+            dt = S.calculate_timestep()
+            (x, y, m, rsm), ind = bodies_at(t)
+            ctx.set_bodies(x, y, m, rsm, ind)
+            if leapfrog:
+                (xm, ym, mm, rm), _ = bodies_at(t + 0.5 * dt)
+                ctx.set_bodies_midstep(xm, ym, mm, rm)
+            ctx.step(dt)
+            ctx.post(dt)
+            t += dt
+            dts.append(dt)
+        outs.append((S.gather(), dts))
+        ctx.close()
+    _check(outs, ("sigma", "vrad", "vazi", "energy") if adiabatic else ("sigma", "vrad", "vazi"))
+    # the potential really moved: the same run with the bodies frozen at t = 0 differs
+    frozen = run_pair(product, product, d, 14, bodies=bodies_at(0.0)[0][:3], nslabs=(1, 0))[0][0]
+    assert rel_err(outs[0][0]["vrad"], frozen["vrad"]) > 1e-6
