@@ -568,3 +568,37 @@ def test_moving_bodies_indirect_term_and_midstep_positions(product, oracle, adia
     # the potential really moved: the same run with the bodies frozen at t = 0 differs
     frozen = run_pair(product, product, d, 14, bodies=bodies_at(0.0)[0][:3], nslabs=(1, 0))[0][0]
     assert rel_err(outs[0][0]["vrad"], frozen["vrad"]) > 1e-6
+
+
+@pytest.mark.parametrize("adiabatic", [False, True])
+def test_recalculate_derived_and_device_pointers(product, oracle, adiabatic):
+    """restart_load's tail (restart.cpp:113): new state grids uploaded, then recalculate_derived_disk_quantities
+    (SourceEuler.cpp:225-249) -- P, T, c_s, H, nu against the oracle; and fcpt_device_ptr: the addresses handed to
+    callers that keep their data on the device really are the grids fcpt_download reads."""
+    import torch
+    from fargocpt_amd import driver
+    d = setups.planet_disk(product, 40, 288, adiabatic=adiabatic)
+    d.rank, d.nranks = 0, 1
+    radii = product.radii(d)
+    fields = product.initial_fields(d.copy(), radii)
+    rng = np.random.default_rng(3)
+    new = [f * (1.0 + 0.2 * rng.random(f.shape)) for f in fields]
+    derived = {}
+    for name, L in (("hip", product), ("oracle", oracle)):
+        ctx = driver.make_context(L, d, fields=fields, radii=radii)
+        for fid, arr in zip((B.F_SIGMA, B.F_VRAD, B.F_VAZI, B.F_ENERGY), new):
+            ctx.upload(fid, arr)
+        ctx.recalculate_derived()
+        derived[name] = {f: ctx.download(f) for f in (B.F_PRESSURE, B.F_TEMPERATURE, B.F_SOUNDSPEED, B.F_SCALE_HEIGHT, B.F_VISCOSITY)}
+        if name == "hip":
+            ptr, count = ctx.device_ptr(B.F_VRAD)
+            assert count == new[1].size
+
+            class _View:   # torch adopts foreign device memory through the CUDA array interface
+                __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+            onchip = torch.as_tensor(_View(), device="cuda")
+            ctx.synchronize()
+            assert np.array_equal(onchip.cpu().numpy().reshape(new[1].shape), new[1])
+        ctx.close()
+    for f, a in derived["hip"].items():
+        assert rel_err(a, derived["oracle"][f]) <= 1e-13, f
