@@ -272,6 +272,11 @@ def test_disk_on_body_accel(product, oracle, adiabatic):
         a = [ctx.disk_on_body_accel(1.0, 0.0, 1.0),                           # H-based smoothing per cell
              ctx.disk_on_body_accel(1.0, 0.0, 1.0, 0.6 * 0.05, 0.5 * hill),   # planet-location + cubic smoothing
              ctx.disk_on_body_accel(0.0, 0.0, 0.0, 0.0, 0.0)]                 # the star, no smoothing
+        rng = np.random.default_rng(11)   # bodies anywhere: inside the inner hole, between rings, beyond the disk
+        for _ in range(24):
+            r, ph = rng.uniform(0.05, 3.5), rng.uniform(0.0, 2 * np.pi)
+            fixed = float(rng.choice([-1.0, 0.0, 0.03]))
+            a.append(ctx.disk_on_body_accel(r * np.cos(ph), r * np.sin(ph), r, fixed, float(rng.choice([0.0, 0.4 * hill]))))
         sig = ctx.download(B.F_SIGMA)
         res.append((a, sig))
         ctx.close()
