@@ -78,6 +78,10 @@ def draw(lib, seed):
     # fused transport hands over to its fallback kernels past the shear limit)
     global _EXTRA
     _EXTRA = {"dt_scale": pick(1.0, 1.0, 1.0, 2.0, 3.5) if WIDE else 1.0}
+    if WIDE and adiabatic and planet and rng.integers(3) == 0:
+        # irradiation_single (SourceEuler.cpp:538-612): a hot star and a warm planet with a ramp-up time
+        _EXTRA["irradiation"] = ([pick(4000.0, 10000.0) / setups.TEMP0_K, pick(0.0, 1500.0) / setups.TEMP0_K],
+                                 [4.65e-3, 4.8e-4], [0.0, pick(0.0, 0.01)])
     return d, nslabs, planet
 
 

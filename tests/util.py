@@ -28,7 +28,8 @@ def perturb(fields, d, amp=1e-3):
     return sigma, vrad, vazi, energy
 
 
-def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=(1, 1), dt_scale=1.0, noise=0.0):
+def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=(1, 1), dt_scale=1.0, noise=0.0,
+             irradiation=None):
     """Advance the same initial state `nsteps` with two libraries; returns the two global
     states and the two dt histories."""
     outs = []
@@ -54,7 +55,7 @@ def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=
             sl = slice(s.imin, s.imin + s.nr)
             sub = (fields[0][sl], fields[1][s.imin:s.imin + s.nr + 1], fields[2][sl], fields[3][sl])
             sub = tuple(np.ascontiguousarray(x) for x in sub)
-            ctxs.append(driver.make_context(L, dd, fields=sub, radii=radii, bodies=bodies))
+            ctxs.append(driver.make_context(L, dd, fields=sub, radii=radii, bodies=bodies, irradiation=irradiation))
         S = driver.SlabSet(ctxs)
         S.dt_scale = dt_scale
         S.prepare()
