@@ -78,6 +78,13 @@ def draw(lib, seed):
     # fused transport hands over to its fallback kernels past the shear limit)
     global _EXTRA
     _EXTRA = {"dt_scale": pick(1.0, 1.0, 1.0, 2.0, 3.5) if WIDE else 1.0}
+    if WIDE:   # initial-condition switches (init.cpp:255-343)
+        d.initialize_pure_keplerian = int(rng.integers(4) == 0)
+        d.initialize_vradial_zero = int(rng.integers(4) == 0)
+        if rng.integers(6) == 0:
+            d.set_sigma0, d.disk_mass = 1, pick(0.01, 0.002)
+        if rng.integers(8) == 0:
+            d.ic, d.disk_mass = B.IC_SPREADING_RING, 1.0e-3
     if WIDE and adiabatic and planet and rng.integers(3) == 0:
         # irradiation_single (SourceEuler.cpp:538-612): a hot star and a warm planet with a ramp-up time
         _EXTRA["irradiation"] = ([pick(4000.0, 10000.0) / setups.TEMP0_K, pick(0.0, 1500.0) / setups.TEMP0_K],
