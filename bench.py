@@ -36,7 +36,6 @@ ALGO_DOUBLES = {
     "k_transport_theta2": (10, 12),  # read 5(6) -> write 5(6) (shifted)
     "k_velocities": (8, 10),         # read 5(6) -> write vr,vphi,Sigma(,e)
     "k_source_march": (6, 6),            # read Sigma,Phi,vr,vphi -> write vr,vphi (isothermal one-pass source step)
-    "k_transport_theta_fused": (11, 13),  # read 5(6) + vphi -> write 5(6), both passes + shift
     "k_transport_theta_march": (9, 11),   # read 5(6) + vphi -> write vr,vphi,Sigma(,e): passes C and D of the model
     "k_transport_fused": (6, 8),          # read Sigma,vr,vphi(,e) -> write Sigma,vr,vphi(,e): passes B+C+D in one kernel
     "k_src_fused": (7, 7), "k_av_fused": (5, 7), "k_visc_fused": (6, 7),

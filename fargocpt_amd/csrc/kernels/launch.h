@@ -402,7 +402,8 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
     ThetaOut outA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
     ThetaSet inA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
     ThetaOut outB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
-    // fused azimuthal sweep when a lane-chunk size fits the ring, else the two-pass kernels
+    // ring-marching azimuthal kernel when a lane-chunk size fits the ring, else (and with FCPT_THETA_MARCH=0 or
+    // FCPT_THETA_FUSED=0) the per-pass kernels
     int C = 0, periodic = 0;
     for (int c : {1, 2, 4})
         if (!C && P.nphi % c == 0 && P.nphi <= 64 * c && (c == 1 || P.nphi / c >= 1)) {
@@ -426,28 +427,6 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
         Wm.vazi = P.vazi == W.vazi ? W.vazi_b : W.vazi;
         res.marched = launch_theta_march(P, Wm, C, periodic, 1, nullptr, st);
         res.vrad = Wm.vrad, res.vazi = Wm.vazi;
-    } else if (C) {
-        const int tstride = 64 * C - 2 * THETA_HALO;
-        const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
-        const int waves = P.nr * tiles;
-        const dim3 grid((waves + 3) / 4), block(256);
-#define FUSED(CC)                                                                                      \
-    if (P.adiabatic)                                                                                   \
-        KLAUNCH(KID_THETA_FUSED, (k_transport_theta_fused<CC, true>), grid, block, P, inB, outA, tiles, periodic); \
-    else                                                                                               \
-        KLAUNCH(KID_THETA_FUSED, (k_transport_theta_fused<CC, false>), grid, block, P, inB, outA, tiles, periodic);
-        if (C == 1) {
-            FUSED(1)
-        } else if (C == 2) {
-            FUSED(2)
-        } else {
-            FUSED(4)
-        }
-#undef FUSED
-        if (W.damp_in_step)
-            LAUNCH2D_T(KID_VELOCITIES, k_velocities, true, P.nr, W, inA, (const double *)P.vrad);
-        else
-            LAUNCH2D_T(KID_VELOCITIES, k_velocities, false, P.nr, W, inA, (const double *)P.vrad);
     } else {
         LAUNCH2D_T(KID_THETA1, k_transport_theta, 1, P.nr, P, inB, outA);
         LAUNCH2D_T(KID_THETA2, k_transport_theta, 2, P.nr, P, inA, outB);

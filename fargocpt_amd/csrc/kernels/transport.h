@@ -359,175 +359,6 @@ template <int PASS, bool ROWU> __global__ void k_transport_theta(const Dev P, Th
 }
 
 
-// ---------------------------------------------------------------------------
-// OneWindTheta (:270-288) in ONE kernel: residual pass, uniform pass and the integer
-// shift.  A wavefront owns a segment of one ring; every lane keeps C contiguous cells of
-// all transported quantities in registers.  Nothing is computed twice: a lane evaluates the
-// limited slope of its own cells and the star state / flux at the lower face of its own
-// cells; the left neighbour's edge value and slope and the right neighbour's first flux
-// arrive by wavefront shuffle (no LDS, no barriers).
-//   * "periodic" mode (Nphi <= 64 C, Nphi % C == 0): one wavefront holds the whole ring and
-//     the shuffles wrap around.
-//   * tiled mode: each pass invalidates two cells at either end of a segment (their stencil
-//     leaves the segment), so segments of 64 C cells advance by 64 C - 8 and only the inner
-//     cells are stored.
-// Reads set B (+ v_phi, <v_phi>, Nshift), writes set A: 11 (13) doubles per cell.
-#define THETA_HALO 4
-template <int C, bool ADI>
-__global__ void __launch_bounds__(256) k_transport_theta_fused(const Dev P, ThetaSet in, ThetaOut out,
-                                                              int tiles, int periodic)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int i = wave / tiles;
-    if (i >= P.nr)
-        return;
-    const int tile = wave - i * tiles;
-    const int nphi = P.nphi;
-    const int nl = periodic ? nphi / C : 64;                    // lanes that own cells
-    const int stride = periodic ? nphi : 64 * C - 2 * THETA_HALO;
-    const int a = periodic ? 0 : tile * stride - THETA_HALO;    // first cell of the segment
-    const bool act = lane < nl;
-    const int ln = act ? lane : 0;
-    int lsrc_l = ln - 1, lsrc_r = ln + 1;
-    if (periodic) {
-        lsrc_l = lsrc_l < 0 ? nl - 1 : lsrc_l;
-        lsrc_r = lsrc_r >= nl ? 0 : lsrc_r;
-    } else {
-        lsrc_l = lsrc_l < 0 ? 0 : lsrc_l;
-        lsrc_r = lsrc_r > 63 ? 63 : lsrc_r;
-    }
-    const double dt = P.clk->dt;
-    const int row = i * nphi;
-    // all cell indices of a segment lie in (-nphi, 2 nphi): one conditional fold replaces '%'
-    auto wrap = [nphi](int j) { return j < 0 ? j + nphi : (j >= nphi ? j - nphi : j); };
-
-    int idx[C];
-    double S[C], Q[4][C], E[C], V[C];
-    const double mean = P.vmean_c[i];
-    const double vconst = P.vconst_c[i];
-    const double vadd = P.fast_transport ? 0.0 : vconst; // ComputeConstantResidual, non-FARGO branch
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        idx[c] = wrap(a + ln * C + c);
-        const int g = row + idx[c];
-        S[c] = in.sig[g];
-        Q[0][c] = in.rmp[g];
-        Q[1][c] = in.rmm[g];
-        Q[2][c] = in.lp[g];
-        Q[3][c] = in.lm[g];
-        E[c] = ADI ? in.e[g] : 0.0;
-        V[c] = vadd + (P.vazi[g] - mean); // residual velocity at the lower face of cell c
-    }
-    const double dxtheta = P.dphi * P.Rmed[i];
-    const double invdxtheta = 1.0 / dxtheta;
-    const double dxrad = (P.Rsup[i] - P.Rinf[i]) * dt;
-    const double invsurf = P.InvSurf[i];
-
-    // ComputeStarTheta (:416-466) + the flux of VanLeerTheta (:655-658) at the lower faces of
-    // the lane's cells for the array W[] (own cells); fac[c] = dxrad * rho*(c) * v(c) (or dxrad
-    // v(c) for the density itself).  fl[C] is the right neighbour's first flux.
-#define THETA_FLUX(fl, st, W, fac, HAVE_ST)                                                        \
-    {                                                                                               \
-        const double wl = __shfl(W[C - 1], lsrc_l, 64); /* cell -1 */                               \
-        const double wr = __shfl(W[0], lsrc_r, 64);     /* cell C  */                               \
-        double dq[C];                                                                               \
-        _Pragma("unroll") for (int c = 0; c < C; ++c)                                               \
-        {                                                                                           \
-            const double wm = c == 0 ? wl : W[c == 0 ? 0 : c - 1];                                 \
-            const double wp = c == C - 1 ? wr : W[c == C - 1 ? C - 1 : c + 1];                      \
-            dq[c] = 0.5 * limiter(P.limiter, wp - W[c], W[c] - wm) * invdxtheta;                    \
-        }                                                                                           \
-        const double dql = __shfl(dq[C - 1], lsrc_l, 64); /* slope of cell -1 */                    \
-        _Pragma("unroll") for (int c = 0; c < C; ++c)                                               \
-        {                                                                                           \
-            const double xa = up[c] ? (c == 0 ? wl : W[c == 0 ? 0 : c - 1]) : W[c];                 \
-            const double sl = up[c] ? (c == 0 ? dql : dq[c == 0 ? 0 : c - 1]) : dq[c];              \
-            const double star = xa + dist[c] * sl;                                                  \
-            if (HAVE_ST)                                                                            \
-                st[c] = star;                                                                       \
-            fl[c] = (HAVE_ST) ? 0.0 : fac[c] * star;                                                \
-        }                                                                                           \
-    }
-
-    for (int pass = 1; pass <= 2; ++pass) {
-        if (pass == 2) {
-            if (!P.fast_transport)
-                break; // NoSplitAdvection: the uniform pass is skipped (:646)
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                V[c] = vconst;
-        }
-        // per-face upwind data shared by all quantities
-        bool up[C];
-        double dist[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const double ksi = V[c] * dt;
-            up[c] = ksi > 0.0;
-            dist[c] = up[c] ? (dxtheta - ksi) : -(dxtheta + ksi);
-        }
-        double rho[C], rS[C], dummy[C];
-        THETA_FLUX(dummy, rho, S, dummy, true); // DensityStar at the lower faces
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-            rS[c] = fast_rcp(S[c]);
-        // varq = dxrad * Q* * rho* * v  (:655-658), evaluated as ((dxrad Q*) rho*) v
-#define THETA_Q(X)                                                                                  \
-        {                                                                                           \
-            double W[C], fl[C + 1], qs[C];                                                          \
-            _Pragma("unroll") for (int c = 0; c < C; ++c) W[c] = X[c] * rS[c];                      \
-            THETA_FLUX(fl, qs, W, dummy, true);                                                     \
-            _Pragma("unroll") for (int c = 0; c < C; ++c) fl[c] = dxrad * qs[c] * rho[c] * V[c];    \
-            fl[C] = __shfl(fl[0], lsrc_r, 64);                                                      \
-            _Pragma("unroll") for (int c = 0; c < C; ++c)                                           \
-            {                                                                                       \
-                double varq = fl[c];                                                                \
-                varq -= fl[c + 1];                                                                  \
-                X[c] += varq * invsurf;                                                             \
-            }                                                                                       \
-        }
-        THETA_Q(Q[0]);
-        THETA_Q(Q[1]);
-        THETA_Q(Q[2]);
-        THETA_Q(Q[3]);
-        if (ADI)
-            THETA_Q(E);
-        {
-            double fl[C + 1];
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                fl[c] = dxrad * 1.0 * rho[c] * V[c];
-            fl[C] = __shfl(fl[0], lsrc_r, 64);
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                double varq = fl[c];
-                varq -= fl[c + 1];
-                S[c] += varq * invsurf;
-            }
-        }
-#undef THETA_Q
-    }
-#undef THETA_FLUX
-    // AdvectSHIFT (:238-268): cell j lands in j + Nshift (Nshift folded into [0, nphi) once)
-    int nshift = P.nshift_c[i] % nphi;
-    nshift = nshift < 0 ? nshift + nphi : nshift;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const int pos = lane * C + c;
-        const bool valid = act && (periodic || (pos >= THETA_HALO && pos < 64 * C - THETA_HALO));
-        if (valid) {
-            const int g = row + wrap(idx[c] + nshift);
-            out.sig[g] = S[c];
-            out.rmp[g] = Q[0][c];
-            out.rmm[g] = Q[1][c];
-            out.lp[g] = Q[2][c];
-            out.lm[g] = Q[3][c];
-            if (ADI)
-                out.e[g] = E[c];
-        }
-    }
-}
 
 // compute_velocities_from_momenta (:498-535) + assure_minimum_value and the
 // temperature floor/ceiling of Transport (:121-131); reads set B, writes the state.
