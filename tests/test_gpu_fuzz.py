@@ -168,6 +168,9 @@ def test_random_configuration_device_loop(product, oracle, seed):
         pytest.skip("the oracle itself left the finite range: not a usable draw")
     a = _device_loop(product, d, bodies, 12)
     fields = ("sigma", "vrad", "vazi") + (("energy",) if d.eos == B.EOS_IDEAL else ())
+    if WIDE:
+        a2 = _device_loop(product, d, bodies, 12)
+        assert a2["time"] == a["time"] and all(np.array_equal(a2[k], a[k], equal_nan=True) for k in fields), f"seed {seed}: run-to-run difference"
     errs = {k: rel_err(a[k], b[k]) for k in fields}
     terr = abs(a["time"] - b["time"]) / abs(b["time"])
     tol, growth = _tolerance(lambda noise: _device_loop(oracle, d, bodies, 12, noise), b, fields, max(max(errs.values()), 0.1 * terr))
