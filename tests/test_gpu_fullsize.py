@@ -122,3 +122,21 @@ def test_radial_slabs_at_full_size(product, nphi, nslabs, adiabatic):
     assert np.allclose(dt1, dtn, rtol=1e-12, atol=0)
     for k in ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ()):
         assert rel_err(many[k], one[k]) <= 1e-12, k
+
+
+@pytest.mark.parametrize("adiabatic", [False, True])
+def test_bench_loop_is_reproducible_bit_for_bit(product, adiabatic):
+    """Every reduction of the path runs in a fixed order: the bench workload (device-resident loop, 40 steps)
+    run twice gives identical bits.  A race between wavefronts -- the failure mode the small grids of the parity
+    tests are least likely to show -- would not."""
+    d = setups.planet_disk(product, NR, NPHI if not adiabatic else 3072, adiabatic=adiabatic)
+    d0 = d.copy()
+    radii = product.radii(d0)
+    fields = perturb(product.initial_fields(d0, radii), d0, 1e-3)
+    bodies = setups.jupiter_bodies(d0)
+    a, _, ta = _run(product, d0, fields, radii, 40, bodies=bodies, device_loop=True)
+    b, _, tb = _run(product, d0, fields, radii, 40, bodies=bodies, device_loop=True)
+    assert ta == tb
+    for k in ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ()):
+        assert np.array_equal(a[k], b[k]), k
+    assert all(np.isfinite(v).all() for v in a.values())
