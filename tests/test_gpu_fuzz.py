@@ -177,3 +177,68 @@ def test_random_configuration_device_loop(product, oracle, seed):
     assert terr <= 10 * tol, f"seed {seed}: time differs by {terr:.3e} (growth {growth:.1e})"
     for k in fields:
         assert errs[k] <= tol, f"seed {seed}: {k}: {errs[k]:.3e} (tolerance {tol:.1e}, growth {growth:.1e})"
+
+
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + max(40, NSEEDS // 4)))
+def test_random_slab_overlap_paths(product, seed, monkeypatch):
+    """The two overlap devices of the N > 1 loop on random draws and slab positions: fcpt_cfl_begin (interior
+    rings while the ghost rings travel) and fcpt_step_device_begin / _end (interior transport chunks on the side
+    stream) must leave the bits of the plain sequence -- state, packed ghost rings, dt -- whatever the
+    configuration, including those where they have to decline (leapfrog, narrow rings, damping outside the
+    step kernels)."""
+    import torch
+    from fargocpt_amd import driver
+    d, _, planet = draw(product, seed)
+    rng = np.random.default_rng(77 + seed)
+    nranks = int(rng.integers(2, 4))
+    rank = int(rng.integers(0, nranks))
+    d.nr_global = max(d.nr_global, 30) * nranks
+    d.rank, d.nranks = rank, nranks
+    radii = product.radii(d)
+    if not np.isfinite(radii).all():
+        pytest.skip("NaN radii: refused at create time (covered elsewhere)")
+    from tests.util import perturb
+    fields = perturb(product.initial_fields(d.copy(), radii), d, 1e-3)
+    bodies = setups.jupiter_bodies(d) if planet else None
+    got = []
+    for overlap in (True, False):
+        monkeypatch.setenv("FCPT_CFL_SPLIT", "1" if overlap else "0")
+        ctx = driver.make_context(product, d, fields=fields, radii=radii, bodies=bodies)
+        cnt = ctx.exchange_count()
+        bufs = [torch.zeros(cnt, dtype=torch.float64, device="cuda") if has else None
+                for has in (rank > 0, rank < nranks - 1)]
+        ptr = lambda b: None if b is None else b.data_ptr()
+        dt_dev = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            ctx.calculate_timestep(ctx.cfl())
+        hist, packed = [], []
+        for n in range(6):
+            ctx.cfl_device(dt_dev.data_ptr())
+            ctx.calculate_timestep_device(dt_dev.data_ptr())
+            if overlap:
+                ctx.step_device_begin()
+                ctx.exchange_pack(ptr(bufs[0]), ptr(bufs[1]))
+                ctx.step_device_end()
+                ctx.cfl_begin()
+            else:
+                ctx.step_device()
+                ctx.exchange_pack(ptr(bufs[0]), ptr(bufs[1]))
+            ctx.synchronize()
+            packed.append([None if b is None else b.cpu().numpy().copy() for b in bufs])
+            for b in bufs:                  # stand-in for the neighbours: the ghost rows get new values
+                if b is not None:
+                    b.mul_(1.0 + 1.0e-6)
+            torch.cuda.synchronize()
+            ctx.exchange_unpack(ptr(bufs[0]), ptr(bufs[1]))
+            ctx.post_device()
+            hist.append(float(dt_dev.cpu()[0]))
+        st = ctx.state()
+        st["time"] = ctx.clock.time
+        got.append((st, hist, packed))
+        ctx.close()
+    assert got[0][1] == got[1][1] or (np.isnan(got[0][1]).any() and np.isnan(got[1][1]).any())
+    for k, v in got[0][0].items():
+        assert np.array_equal(v, got[1][0][k], equal_nan=True), k
+    for pa, pb in zip(got[0][2], got[1][2]):
+        for x, y in zip(pa, pb):
+            assert (x is None and y is None) or np.array_equal(x, y, equal_nan=True)
