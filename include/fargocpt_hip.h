@@ -393,11 +393,12 @@ int fcpt_snap_to_monitor(const fcpt_ctx *ctx, double cfl_dt, double *step_dt);
  * dt/2, boundary (final=false), Transport with dt, potential at mid-step, compute_pressure,
  * gas kick 2/2 with dt/2.  Asynchronous on the context's stream.  Advances time by dt.
  *
- * The fused transport kernel relies on |Nshift[i] - Nshift[i-1]| <= 1, which the FARGO shear term of the
- * CFL condition (src/cfl.cpp:207-220) guarantees for its own dt.  A dt that is not known to be the
- * policy's (not <= the value fcpt_calculate_timestep returned last, or CFL > 0.8) gets the two-kernel
- * transport queued behind as a device-side fallback, so any dt is computed correctly; if the limit is
- * ever exceeded without that fallback, the next synchronising call returns FCPT_ESHEAR. */
+ * The fused transport kernel handles |Nshift[i] - Nshift[i-1]| <= 1, which the FARGO shear term of the CFL
+ * condition (src/cfl.cpp:207-220) makes the normal case; the two-kernel transport is queued behind it as a
+ * device-side fallback and runs only when a ring pair exceeds that (a dt beyond the CFL step, or a source step
+ * that changed v_phi violently), so every step is computed as the reference does.  FCPT_TRANSPORT_FALLBACK=0
+ * (environment) drops the two idle launches for flows known to be benign; if the limit is then ever exceeded,
+ * the next synchronising call returns FCPT_ESHEAR. */
 int fcpt_step(fcpt_ctx *ctx, double dt);
 
 /* CommunicateBoundaries, device side (src/commbound.cpp:108-125,163-180):

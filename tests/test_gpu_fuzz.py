@@ -201,6 +201,8 @@ def test_random_slab_overlap_paths(product, seed, monkeypatch):
     fields = perturb(product.initial_fields(d.copy(), radii), d, 1e-3)
     bodies = setups.jupiter_bodies(d) if planet else None
     got = []
+    if seed % 2:   # half of the draws without the fallback kernels, so that the transport really splits
+        monkeypatch.setenv("FCPT_TRANSPORT_FALLBACK", "0")
     for overlap in (True, False):
         monkeypatch.setenv("FCPT_CFL_SPLIT", "1" if overlap else "0")
         ctx = driver.make_context(product, d, fields=fields, radii=radii, bodies=bodies)
@@ -232,7 +234,12 @@ def test_random_slab_overlap_paths(product, seed, monkeypatch):
             ctx.exchange_unpack(ptr(bufs[0]), ptr(bufs[1]))
             ctx.post_device()
             hist.append(float(dt_dev.cpu()[0]))
-        st = ctx.state()
+        try:
+            st = ctx.state()
+        except B.FcptError as err:
+            ctx.close()
+            assert "FCPT_ESHEAR" in str(err) and seed % 2
+            pytest.skip("beyond the one-lane shift without the fallback kernels")
         st["time"] = ctx.clock.time
         got.append((st, hist, packed))
         ctx.close()

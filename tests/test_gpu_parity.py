@@ -464,12 +464,13 @@ def test_wide_rings_6144(product, oracle, adiabatic):
 
 
 @pytest.mark.parametrize("adiabatic,rank,nranks", [(False, 1, 3), (True, 1, 3), (False, 0, 2), (False, 1, 2)])
-def test_step_split_around_the_ghost_exchange(product, adiabatic, rank, nranks):
+def test_step_split_around_the_ghost_exchange(product, adiabatic, rank, nranks, monkeypatch):
     """fcpt_step_device_begin / _end: the transport chunks with the neighbours' ghost rings on the caller's
     stream, the others on the library's side stream under the pack kernel.  Same bits as fcpt_step_device, the
     packed rings included, and really two launches of the marching kernel per step."""
     import torch
     from fargocpt_amd import driver
+    monkeypatch.setenv("FCPT_TRANSPORT_FALLBACK", "0")   # the split needs the fused kernel alone (benign flow here)
     d = setups.planet_disk(product, nranks * 120, 320, adiabatic=adiabatic)
     d.rank, d.nranks = rank, nranks
     radii = product.radii(d)
