@@ -11,7 +11,7 @@ from typing import Optional
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OVERLAP = 7
 GEOM_PAD = 15
 MAX_BODIES = 8
@@ -30,10 +30,12 @@ DAMP_NONE, DAMP_REFERENCE, DAMP_ZERO, DAMP_MEAN = range(4)
 IC_PROFILE, IC_SPREADING_RING, IC_SHOCKTUBE = range(3)
 (F_SIGMA, F_VRAD, F_VAZI, F_ENERGY, F_PRESSURE, F_SOUNDSPEED, F_SCALE_HEIGHT, F_VISCOSITY,
  F_TEMPERATURE, F_POTENTIAL, F_SIGMA0, F_VRAD0, F_VAZI0, F_ENERGY0, F_QPLUS, F_QMINUS,
- F_VISC_CFAC_PHI, F_VISC_CFAC_R) = range(18)
-VECTOR_FIELDS = (F_VRAD, F_VRAD0)
+ F_VISC_CFAC_PHI, F_VISC_CFAC_R, F_MASSFLOW) = range(19)
+VECTOR_FIELDS = (F_VRAD, F_VRAD0, F_MASSFLOW)
+COMM_ID_BYTES = 128
 
-ERRORS = {-1: "FCPT_EINVAL", -2: "FCPT_ENOMEM", -3: "FCPT_EHIP", -4: "FCPT_ESPLIT", -5: "FCPT_ENODEV", -6: "FCPT_ESHEAR"}
+ERRORS = {-1: "FCPT_EINVAL", -2: "FCPT_ENOMEM", -3: "FCPT_EHIP", -4: "FCPT_ESPLIT", -5: "FCPT_ENODEV", -6: "FCPT_ESHEAR",
+          -7: "FCPT_ECOMM"}
 
 _i32, _u32, _u64, _f64 = C.c_int32, C.c_uint32, C.c_uint64, C.c_double
 
@@ -173,6 +175,12 @@ class Library:
     def create(self, d: Desc, radii: np.ndarray) -> "Context":
         return Context(self, d, radii)
 
+    def comm_unique_id(self) -> bytes:
+        """ncclGetUniqueId: slab 0 calls it and hands the bytes to every slab (fcpt_comm_init)."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        self.check(self.fn("comm_unique_id")(buf), "comm_unique_id")
+        return buf.raw
+
 
 class Context:
     """Owns one fcpt_ctx (one radial slab on one device)."""
@@ -224,6 +232,30 @@ class Context:
     def synchronize(self):
         self._call("synchronize")
 
+    def set_option(self, name: str, value: int):
+        self._call("set_option", C.c_char_p(name.encode()), _i32(value))
+
+    def get_option(self, name: str) -> int:
+        v = _i32()
+        self._call("get_option", C.c_char_p(name.encode()), C.byref(v))
+        return v.value
+
+    # radial slabs over RCCL inside the library
+    def comm_init(self, unique_id: bytes):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._call("comm_init", C.c_char_p(unique_id))
+
+    def comm_destroy(self):
+        self._call("comm_destroy")
+
+    def exchange(self):
+        self._call("exchange")
+
+    def cfl_allreduce(self, blocking: bool = True):
+        v = _f64()
+        self._call("cfl_allreduce", C.byref(v) if blocking else None)
+        return v.value if blocking else None
+
     def set_bodies(self, x, y, m, rsm=None, indirect=(0.0, 0.0)):
         x, y, m = (np.ascontiguousarray(v, dtype=np.float64) for v in (x, y, m))
         rsm = np.zeros_like(x) if rsm is None else np.ascontiguousarray(rsm, dtype=np.float64)
@@ -269,8 +301,8 @@ class Context:
     def cfl_begin(self):
         self._call("cfl_begin")
 
-    def calculate_timestep_device(self, d_cfl_global: int):
-        self._call("calculate_timestep_device", C.c_void_p(int(d_cfl_global)))
+    def calculate_timestep_device(self, d_cfl_global: Optional[int] = None):
+        self._call("calculate_timestep_device", C.c_void_p(int(d_cfl_global)) if d_cfl_global else None)
 
     def step_device(self):
         self._call("step_device")

@@ -8,6 +8,7 @@
 #include <new>
 #include <vector>
 
+#include "fcpt_comm.h"
 #include "fcpt_kernels.h"
 
 using namespace fcpt;
@@ -47,6 +48,8 @@ struct fcpt_ctx {
     bool stepped = false; // fcpt_step ran since the last fcpt_post
     bool cfl_interior = false; // fcpt_cfl_begin evaluated the interior rings of the current state
     bool damp_any = false;     // this slab holds rings of a damping zone
+    bool massflow_valid = false; // the MASSFLOW grid holds the flux of the last Transport()
+    bool damp_foldable = false; // ... and its damping can be folded into the transport (no "mean" target, Euler)
     // fcpt_step_device_begin: the interior chunks of the transport run on `side` while the caller's stream
     // marches the chunks with the neighbours' ghost rings, packs and sends them
     hipStream_t side = nullptr;
@@ -56,15 +59,59 @@ struct fcpt_ctx {
     // leapfrog: bodies at the mid-step time (simulation.cpp:359-366)
     bool has_mid = false;
     double mx[FCPT_MAX_BODIES], my[FCPT_MAX_BODIES], mm[FCPT_MAX_BODIES], mrsm[FCPT_MAX_BODIES];
+    // radial slabs over RCCL (fcpt_comm_init): communicator, packed ghost-ring buffers [send inner, send outer,
+    // recv inner, recv outer], the device scalar of the MIN all-reduce, a stream for transfers that overlap the CFL
+    Comm *comm = nullptr;
+    double *xbuf[4] = {};
+    double *d_cfl = nullptr;
+    int peer_inner = -1, peer_outer = -1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t e_packed = nullptr, e_received = nullptr;
+    int device = 0; // HIP device the context was created on
 };
 
 #define DOB_ROWS_HOST 8 /* = DOB_ROWS of k_disk_on_body */
 namespace {
 
+int *option_slot(Options &o, const char *name)
+{
+#define X(n)                     \
+    if (!std::strcmp(name, #n)) \
+        return &o.n;
+    FCPT_OPTION_NAMES
+#undef X
+    return nullptr;
+}
+
+// defaults of the switches: FCPT_<NAME> in the environment, read here and nowhere else
+void options_from_environment(Options &o)
+{
+    o.transport_fused = o.transport_rows = o.source_rows = o.theta_rows = -1;
+    o.transport_fallback = o.transport_split = o.fused_source = o.march_source = o.march_source_adi = 1;
+    o.theta_march = o.theta_fused = o.cfl_rings = o.cfl_split = o.source_ring_parts = o.fused_damping = 1;
+    o.comm_overlap = 0;
+    o.comm_loopback = 0;
+    o.graph_steps = -1;
+#define X(n)                                                           \
+    {                                                                  \
+        char env[64] = "FCPT_";                                        \
+        size_t k = 5;                                                  \
+        for (const char *q = #n; *q && k + 1 < sizeof(env); ++q)       \
+            env[k++] = (char)((*q >= 'a' && *q <= 'z') ? *q - 32 : *q); \
+        env[k] = 0;                                                    \
+        if (const char *e = getenv(env))                               \
+            if (e[0])                                                  \
+                o.n = atoi(e);                                         \
+    }
+    FCPT_OPTION_NAMES
+#undef X
+}
+
 // routes this thread's launches to the context's profiler while it is recording
 struct ProfScope {
-    explicit ProfScope(fcpt_ctx *c) { g_prof = c->profiling ? &c->prof : nullptr; }
-    ~ProfScope() { g_prof = nullptr; }
+    Profiler *outer;
+    explicit ProfScope(fcpt_ctx *c) : outer(g_prof) { g_prof = c->profiling ? &c->prof : nullptr; }
+    ~ProfScope() { g_prof = outer; }
 };
 
 template <class T> int dev_alloc(fcpt_ctx *c, T **p, size_t n)
@@ -164,6 +211,27 @@ void join_side(fcpt_ctx *c)
     }
 }
 
+// the context's derived switches after its options changed (fcpt_create, fcpt_set_option)
+void apply_options(fcpt_ctx *c, bool at_create = true)
+{
+    const Options &o = c->P.opt;
+    c->fused_source = o.fused_source != 0;
+    c->march_source = o.march_source != 0;
+    if (c->P.stabilize) // the pseudo-implicit viscosity lives in the per-loop kernels only
+        c->fused_source = c->march_source = false;
+    const bool adi_march =
+        c->P.adiabatic && c->fused_source && c->march_source && c->P.nphi >= 128 && o.march_source_adi != 0;
+    c->P.lazy_derived = adi_march ? 1 : 0;
+    c->P.damp_in_step = (c->damp_foldable && o.fused_damping != 0) ? 1 : 0;
+    c->cfl_interior = false;
+    c->potential_valid = false;
+    c->pressure_valid = false;
+    if (!at_create && c->P.adiabatic && !c->P.lazy_derived) {
+        launch_derived(c->P, c->stream); // the kernels that read c_s, H, nu, T from the grids expect them current
+        c->pressure_valid = true;
+    }
+}
+
 // boundary_conditions.cpp:65-114
 void apply_boundary_view(fcpt_ctx *c, const Dev &P, bool final, bool damping_done = false)
 {
@@ -201,8 +269,9 @@ int read_clock(fcpt_ctx *c, DevClock *out)
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = *c->h_clk;
     if (out->shear_error) {
-        set_error("a step exceeded the FARGO shear limit (|Nshift[i]-Nshift[i-1]| > 1) without fallback kernels; "
-                  "the state is invalid (FCPT_TRANSPORT_FALLBACK=1 forces them)");
+        set_error("a step exceeded the FARGO shear limit (|Nshift[i]-Nshift[i-1]| > 1) with the option "
+                  "transport_fallback = 0, i.e. without the two-kernel transport queued behind the fused one; "
+                  "the state is invalid");
         return FCPT_ESHEAR;
     }
     return FCPT_OK;
@@ -324,12 +393,12 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool spl
         launch_shift_means(Q, st);
         (void)hipEventRecord(c->e_fork, st);
         (void)hipStreamWaitEvent(c->side, c->e_fork, 0);
-        (void)launch_transport(Q, P, shear_safe, c->side, TRANSPORT_INTERIOR);
+        (void)launch_transport(Q, P, c->side, TRANSPORT_INTERIOR);
         (void)hipEventRecord(c->e_join, c->side);
-        tr = launch_transport(Q, P, shear_safe, st, TRANSPORT_EDGES);
+        tr = launch_transport(Q, P, st, TRANSPORT_EDGES);
         c->join_pending = true;
     } else {
-        tr = launch_transport(Q, P, shear_safe, st);
+        tr = launch_transport(Q, P, st);
     }
     if (!tr.marched)
         launch_clock_advance(P.clk, st);
@@ -433,6 +502,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     if (!c)
         return FCPT_ENOMEM;
     c->d = *d;
+    (void)hipGetDevice(&c->device);
     if (int rc = split_domain(*d, c->s)) {
         delete c;
         return rc;
@@ -813,10 +883,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         }
         // leapfrog kicks the gas once more after the transport, so its damping cannot be folded in
         c->damp_any = d->damping && any;
-        P.damp_in_step = (d->damping && any && !mean && d->integrator == FCPT_INTEGRATOR_EULER) ? 1 : 0;
-        if (const char *e = getenv("FCPT_FUSED_DAMPING"))
-            if (e[0] == '0')
-                P.damp_in_step = 0;
+        c->damp_foldable = d->damping && any && !mean && d->integrator == FCPT_INTEGRATOR_EULER;
     }
 
     DevClock clk;
@@ -828,19 +895,46 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         fcpt_destroy(c);
         return FCPT_EHIP;
     }
-    if (const char *e = getenv("FCPT_FUSED_SOURCE"))
-        c->fused_source = e[0] != '0';
-    if (const char *e = getenv("FCPT_MARCH_SOURCE"))
-        c->march_source = e[0] != '0';
-    if (c->P.stabilize) // the pseudo-implicit viscosity lives in the per-loop kernels only
-        c->fused_source = c->march_source = false;
-    {
-        bool adi_march = c->P.adiabatic && c->fused_source && c->march_source && c->P.nphi >= 128;
-        if (const char *e = getenv("FCPT_MARCH_SOURCE_ADI"))
-            adi_march = adi_march && e[0] != '0';
-        c->P.lazy_derived = adi_march ? 1 : 0;
-    }
+    options_from_environment(c->P.opt);
+    apply_options(c);
     *out = c;
+    return FCPT_OK;
+}
+
+int fcpt_set_option(fcpt_ctx *c, const char *name, int32_t value)
+{
+    if (!c || !name)
+        return FCPT_EINVAL;
+    int *slot = option_slot(c->P.opt, name);
+    if (!slot) {
+        set_error("fcpt_set_option: unknown option '%s'", name);
+        return FCPT_EINVAL;
+    }
+    if (*slot == value)
+        return FCPT_OK;
+    if (c->stepped) {
+        set_error("fcpt_set_option between fcpt_step and fcpt_post");
+        return FCPT_EINVAL;
+    }
+    join_side(c);
+    // a switch may change which grids hold the derived quantities: finish what is queued, then start clean
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *slot = value;
+    apply_options(c, false);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_get_option(const fcpt_ctx *c, const char *name, int32_t *value)
+{
+    if (!c || !name || !value)
+        return FCPT_EINVAL;
+    const int *slot = option_slot(const_cast<Options &>(c->P.opt), name);
+    if (!slot) {
+        set_error("fcpt_get_option: unknown option '%s'", name);
+        return FCPT_EINVAL;
+    }
+    *value = *slot;
     return FCPT_OK;
 }
 
@@ -848,6 +942,7 @@ int fcpt_destroy(fcpt_ctx *c)
 {
     if (!c)
         return FCPT_OK;
+    (void)fcpt_comm_destroy(c);
     for (void *p : c->allocs)
         (void)hipFree(p);
     if (c->h_clk)
@@ -940,6 +1035,15 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
     join_side(c);
     HIPCHK(hipMemcpyAsync(c->grid[f], host, grid_count(c, f) * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (f == FCPT_F_SIGMA || f == FCPT_F_VRAD || f == FCPT_F_VAZI || f == FCPT_F_ENERGY) {
+        // a replaced state grid: nothing derived from the old one may be reused.  The non-lazy ideal-EOS paths read
+        // c_s, H, nu, T from grids that only fcpt_init_physics / fcpt_recalculate_derived / fcpt_post refresh --
+        // that contract (restart_load, restart.cpp:18-139) stays; what the library evaluates lazily is redone.
+        c->pressure_valid = false;
+        c->potential_valid = false;
+        c->stepped = false;
+        c->massflow_valid = false;
+    }
     if (f == FCPT_F_SCALE_HEIGHT)
         c->potential_valid = false;
     c->cfl_interior = false;
@@ -1105,10 +1209,7 @@ void enqueue_cfl(fcpt_ctx *c, int apply_policy)
 } // namespace
 extern "C" {
 
-// condition_cfl for the rings that neither the ghost exchange nor the boundary kernels touch, to be queued between
-// fcpt_exchange_pack and the wait for the neighbours' rings: it runs while they are on the wire.  The next
-// fcpt_cfl / fcpt_cfl_device evaluates the remaining rings and reduces.  A no-op (the whole CFL runs later)
-// whenever that split would not see the final state: damping outside the step kernels, narrow rings, ...
+// recalculate_derived_disk_quantities (SourceEuler.cpp:225-249) after the state grids were replaced from outside
 int fcpt_recalculate_derived(fcpt_ctx *c)
 {
     if (!c)
@@ -1128,6 +1229,10 @@ int fcpt_recalculate_derived(fcpt_ctx *c)
     return FCPT_OK;
 }
 
+// condition_cfl for the rings that neither the ghost exchange nor the boundary kernels touch, to be queued between
+// fcpt_exchange_pack and the wait for the neighbours' rings: it runs while they are on the wire.  The next
+// fcpt_cfl / fcpt_cfl_device evaluates the remaining rings and reduces.  A no-op (the whole CFL runs later)
+// whenever that split would not see the final state: damping outside the step kernels, narrow rings, ...
 int fcpt_cfl_begin(fcpt_ctx *c)
 {
     if (!c)
@@ -1137,9 +1242,8 @@ int fcpt_cfl_begin(fcpt_ctx *c)
     const bool state_final = c->stepped && (!c->damp_any || c->P.damp_in_step != 0); // fcpt_post will not damp
     if (!state_final)
         return FCPT_OK;
-    if (const char *e = getenv("FCPT_CFL_SPLIT"))
-        if (e[0] == '0')
-            return FCPT_OK;
+    if (c->P.opt.cfl_split == 0)
+        return FCPT_OK;
     ProfScope prof_scope(c);
     c->cfl_interior = launch_cfl_interior(c->P, c->stream);
     HIPCHK(hipGetLastError());
@@ -1175,6 +1279,8 @@ int fcpt_cfl_device(fcpt_ctx *c, double *d_dt_local)
 
 int fcpt_calculate_timestep_device(fcpt_ctx *c, const double *d_cfl_global)
 {
+    if (c && !d_cfl_global)
+        d_cfl_global = c->d_cfl; // what fcpt_cfl_allreduce left
     if (!c || !d_cfl_global)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
@@ -1371,6 +1477,151 @@ int fcpt_exchange_unpack(fcpt_ctx *c, const double *recv_inner, const double *re
     return FCPT_OK;
 }
 
+// ---- radial slabs over RCCL ----------------------------------------------------------------------------------
+
+int fcpt_comm_unique_id(void *id128)
+{
+    const int rc = comm_unique_id(id128);
+    return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
+}
+
+int fcpt_comm_init(fcpt_ctx *c, const void *id128)
+{
+    if (!c || !id128)
+        return FCPT_EINVAL;
+    if (c->comm) {
+        set_error("fcpt_comm_init: the context already has a communicator");
+        return FCPT_EINVAL;
+    }
+    const bool loopback = c->P.opt.comm_loopback != 0;
+    if (!loopback && c->P.nr < 2 * FCPT_OVERLAP && c->d.nranks > 1)
+        return FCPT_ESPLIT;
+    HIPCHK(hipSetDevice(c->device));
+    // rehearsal on one GPU: a communicator of one rank whose slab sends its ghost rings to itself
+    const int rank = loopback ? 0 : c->d.rank, nranks = loopback ? 1 : c->d.nranks;
+    if (int rc = comm_create(id128, rank, nranks, &c->comm))
+        return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
+    c->peer_inner = loopback ? 0 : (c->s.is_first ? -1 : rank - 1);
+    c->peer_outer = loopback ? 0 : (c->s.is_last ? -1 : rank + 1);
+    uint64_t cnt = 0;
+    (void)fcpt_exchange_count(c, &cnt);
+    int rc = FCPT_OK;
+    for (int k = 0; k < 4 && !rc; ++k)
+        rc = dev_alloc(c, &c->xbuf[k], (size_t)cnt);
+    if (!rc)
+        rc = dev_alloc(c, &c->d_cfl, 1);
+    if (rc)
+        return rc;
+    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->e_packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->e_received, hipEventDisableTiming));
+    return FCPT_OK;
+}
+
+int fcpt_comm_destroy(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    if (c->comm) {
+        join_side(c);
+        (void)hipStreamSynchronize(c->stream);
+        if (c->comm_stream)
+            (void)hipStreamSynchronize(c->comm_stream);
+        comm_destroy(c->comm);
+        c->comm = nullptr;
+    }
+    if (c->comm_stream)
+        (void)hipStreamDestroy(c->comm_stream);
+    if (c->e_packed)
+        (void)hipEventDestroy(c->e_packed);
+    if (c->e_received)
+        (void)hipEventDestroy(c->e_received);
+    c->comm_stream = nullptr;
+    c->e_packed = c->e_received = nullptr;
+    return FCPT_OK; // the ghost buffers go with the context
+}
+
+} // extern "C"
+namespace {
+// commbound.cpp:98-182
+int enqueue_exchange(fcpt_ctx *c)
+{
+    if (!c->comm) {
+        set_error("fcpt_exchange needs fcpt_comm_init");
+        return FCPT_EINVAL;
+    }
+    if (c->peer_inner < 0 && c->peer_outer < 0)
+        return FCPT_OK; // a single slab: CommunicateBoundaries returns at once (commbound.cpp:104)
+    join_side(c);
+    double *s_in = c->peer_inner >= 0 ? c->xbuf[0] : nullptr, *s_out = c->peer_outer >= 0 ? c->xbuf[1] : nullptr;
+    double *r_in = c->peer_inner >= 0 ? c->xbuf[2] : nullptr, *r_out = c->peer_outer >= 0 ? c->xbuf[3] : nullptr;
+    uint64_t cnt = 0;
+    (void)fcpt_exchange_count(c, &cnt);
+    launch_exchange_copy(c->P, s_in, s_out, 0, c->stream);
+    int rc;
+    if (c->P.opt.comm_overlap != 0) {
+        // transfers on the communication stream; under them, on the context's stream, the CFL terms of the rings
+        // that neither the unpack nor the boundary kernels write (fcpt_cfl_begin)
+        HIPCHK(hipEventRecord(c->e_packed, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->e_packed, 0));
+        rc = comm_neighbour_exchange(c->comm, c->peer_inner, s_in, r_in, c->peer_outer, s_out, r_out, (size_t)cnt,
+                                     c->comm_stream);
+        HIPCHK(hipEventRecord(c->e_received, c->comm_stream));
+        if (!rc)
+            rc = fcpt_cfl_begin(c);
+        HIPCHK(hipStreamWaitEvent(c->stream, c->e_received, 0));
+    } else {
+        rc = comm_neighbour_exchange(c->comm, c->peer_inner, s_in, r_in, c->peer_outer, s_out, r_out, (size_t)cnt,
+                                     c->stream);
+    }
+    if (rc)
+        return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
+    launch_exchange_copy(c->P, r_in, r_out, 1, c->stream);
+    return FCPT_OK;
+}
+
+// cfl.cpp:185-379 with the result left in c->d_cfl
+int enqueue_cfl_allreduce(fcpt_ctx *c)
+{
+    enqueue_cfl(c, 0);
+    launch_clock_export_cfl(c->P.clk, c->d_cfl, c->stream);
+    const int rc = comm_allreduce_min(c->comm, c->d_cfl, c->stream);
+    return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
+}
+} // namespace
+extern "C" {
+
+int fcpt_exchange(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    ProfScope prof_scope(c);
+    if (int rc = enqueue_exchange(c))
+        return rc;
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_cfl_allreduce(fcpt_ctx *c, double *dt_global)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    if (!c->comm) {
+        set_error("fcpt_cfl_allreduce needs fcpt_comm_init");
+        return FCPT_EINVAL;
+    }
+    ProfScope prof_scope(c);
+    if (int rc = enqueue_cfl_allreduce(c))
+        return rc;
+    HIPCHK(hipGetLastError());
+    if (dt_global) {
+        HIPCHK(hipMemcpyAsync(&c->h_clk->cfl_dt, c->d_cfl, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *dt_global = c->h_clk->cfl_dt;
+    }
+    return FCPT_OK;
+}
+
 int32_t fcpt_kernel_count(void) { return KID_COUNT; }
 const char *fcpt_kernel_name(int32_t id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
 
@@ -1420,7 +1671,53 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
         return FCPT_EINVAL;
     ProfScope prof_scope(c);
     int64_t n = 0;
-    if (!snap) {
+    const bool slabs = c->comm && (c->peer_inner >= 0 || c->peer_outer >= 0); // this slab has neighbours
+    if (slabs && !snap) {
+        // several slabs, dt never leaves the device: CFL -> MIN over the slabs (cfl.cpp:379) -> policy kernel -> step
+        // -> ghost exchange (simulation.cpp:236) -> post, all on one stream
+        for (; n < nsteps; ++n) {
+            if (int rc = enqueue_cfl_allreduce(c))
+                return rc;
+            launch_clock_policy_ptr(c->P.clk, c->d.cfl_max_var, c->d_cfl, c->stream);
+            enqueue_step(c, true, 0.0, c->d.cfl <= 0.8);
+            if (int rc = enqueue_exchange(c))
+                return rc;
+            enqueue_post(c);
+        }
+        HIPCHK(hipGetLastError());
+    } else if (slabs) {
+        // monitor-time snapping: the reduced dt comes to the host, as in sim::run
+        const double t_final = (double)c->d.nsnapshots * c->d.nmonitor * c->d.monitor_timestep;
+        for (; n < nsteps; ++n) {
+            DevClock k;
+            if (int rc = read_clock(c, &k))
+                return rc;
+            if (t_final > 0 && !(k.time < t_final))
+                break;
+            double cfl_dt, dt, step_dt;
+            if (int rc = fcpt_cfl_allreduce(c, &cfl_dt))
+                return rc;
+            if (int rc = fcpt_calculate_timestep(c, cfl_dt, &dt))
+                return rc;
+            if (int rc = fcpt_snap_to_monitor(c, dt, &step_dt))
+                return rc;
+            const double time_next_monitor = (k.n_monitor + 1) * c->d.monitor_timestep;
+            if (int rc = fcpt_step(c, step_dt))
+                return rc;
+            if (int rc = fcpt_exchange(c))
+                return rc;
+            if (int rc = fcpt_post(c, step_dt))
+                return rc;
+            if (int rc = read_clock(c, &k))
+                return rc;
+            if (std::fabs(time_next_monitor - k.time) < 1e-6 * dt) {
+                fcpt_clock hc = {k.time, k.last_dt, k.n_hydro_iter, k.n_monitor + 1, 0};
+                hc.n_snapshot = hc.n_monitor / (uint32_t)(c->d.nmonitor > 0 ? c->d.nmonitor : 1);
+                if (int rc = fcpt_set_clock(c, &hc))
+                    return rc;
+            }
+        }
+    } else if (!snap) {
         // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
         for (; n < nsteps; ++n) {
             enqueue_cfl(c, 1); // CFL + CalculateTimeStep policy on the device

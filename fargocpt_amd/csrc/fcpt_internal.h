@@ -117,6 +117,34 @@ struct alignas(64) DampRow { // ring i (nr + 1 rows: v_r has row nr)
     double pad[2];
 };
 
+// Kernel-selection switches of one context (fcpt_set_option / fcpt_get_option).  The FCPT_* environment
+// variables of the same names only seed the defaults in fcpt_create; nothing on the launch path reads the
+// environment.  A value of -1 means "not set: the launcher's built-in choice".
+struct Options {
+    int transport_fused;    // 0: off, 1 | 2: k_transport_fused with 1 | 2 cells per lane (rings of >= 256 cells)
+    int transport_rows;     // rings per marching chunk of k_transport_fused
+    int source_rows;        // ... of k_source_march(_adi)
+    int theta_rows;         // ... of k_transport_theta_march
+    int transport_fallback; // 1: the two-kernel transport is queued behind every k_transport_fused
+    int transport_split;    // fcpt_step_device_begin may split the transport around the ghost exchange
+    int fused_source;       // 0: per-loop source kernels
+    int march_source;       // 0: the three fused source kernels instead of the marching one
+    int march_source_adi;   // 0: ... for the ideal EOS only
+    int theta_march;        // 0: per-pass azimuthal kernels
+    int theta_fused;        // 0: same (older name, kept)
+    int cfl_rings;          // 0: k_ring_mean + k_cfl_cells instead of k_cfl_rings
+    int cfl_split;          // fcpt_cfl_begin evaluates the interior rings ahead of the ghost exchange
+    int source_ring_parts;  // 0: the transport's ring mean re-reads v_phi
+    int fused_damping;      // 0: the wave damping as separate kernels in the final boundary call
+    int comm_overlap;       // fcpt_exchange: transfers on the library's communication stream under the interior CFL
+    int comm_loopback;      // rehearsal on one GPU: both "neighbours" of the slab are the slab itself
+    int graph_steps;        // fcpt_run_steps: replay a captured hipGraph of one step (launch-bound narrow grids)
+};
+#define FCPT_OPTION_NAMES                                                                                        \
+    X(transport_fused) X(transport_rows) X(source_rows) X(theta_rows) X(transport_fallback) X(transport_split)    \
+    X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_split)   \
+    X(source_ring_parts) X(fused_damping) X(comm_overlap) X(comm_loopback) X(graph_steps)
+
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.
 struct Dev {
     int nr, nphi;
@@ -201,6 +229,7 @@ struct Dev {
     int nbodies;
     double bx[FCPT_MAX_BODIES], by[FCPT_MAX_BODIES], bm[FCPT_MAX_BODIES], brsm[FCPT_MAX_BODIES];
     double indirect_x, indirect_y;
+    Options opt; // host side only: which kernels the launchers pick
 };
 
 } // namespace fcpt

@@ -55,7 +55,7 @@ struct TransportResult {
     int split;    // only a part of the chunks was marched
 };
 enum { TRANSPORT_ALL = 0, TRANSPORT_EDGES = 1, TRANSPORT_INTERIOR = 2 };
-TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st, int part = TRANSPORT_ALL);
+TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part = TRANSPORT_ALL);
 bool transport_can_split(const Dev &P, bool shear_safe);
 void launch_shift_means(const Dev &P, hipStream_t st);
 void launch_substep3_cooling_only(const Dev &P, hipStream_t st);

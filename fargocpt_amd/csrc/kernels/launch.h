@@ -119,12 +119,9 @@ int launch_source_march(const Dev &P, hipStream_t st)
     if (P.nphi < 128)
         return 0;
     if (P.adiabatic) {
-        if (const char *e = getenv("FCPT_MARCH_SOURCE_ADI"))
-            if (e[0] == '0')
-                return 0;
-        int rows = 24;
-        if (const char *e = getenv("FCPT_SOURCE_ROWS")) // tuning knob
-            rows = atoi(e) > 0 ? atoi(e) : rows;
+        if (P.opt.march_source_adi == 0)
+            return 0;
+        const int rows = P.opt.source_rows > 0 ? P.opt.source_rows : 24;
         const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
         const int chunks = (P.nr + 1 + rows - 1) / rows;
         const dim3 grid((segs * chunks + 3) / 4), block(256);
@@ -144,15 +141,12 @@ int launch_source_march(const Dev &P, hipStream_t st)
 #undef ADIK
         return -segs; // marched, no ring sums
     }
-    int rows = 24; // measured at 2048x4096: 16 / 24 / 32 / 48 / 64 rings -> 0.133 / 0.132 / 0.141 / 0.152 / 0.188 ms
-    if (const char *e = getenv("FCPT_SOURCE_ROWS")) // tuning knob
-        rows = atoi(e) > 0 ? atoi(e) : rows;
+    // measured at 2048x4096: 16 / 24 / 32 / 48 / 64 rings -> 0.133 / 0.132 / 0.141 / 0.152 / 0.188 ms
+    const int rows = P.opt.source_rows > 0 ? P.opt.source_rows : 24;
     const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
     // per-segment ring sums of v_phi, so that the transport's k_ring_mean reads 70 partials per ring
     // instead of the ring itself
-    int ring_sums = segs <= P.ring_pstride;
-    if (const char *e = getenv("FCPT_SOURCE_RING_PARTS"))
-        ring_sums = ring_sums && e[0] != '0';
+    const int ring_sums = segs <= P.ring_pstride && P.opt.source_ring_parts != 0;
     const int chunks = (P.nr + 1 + rows - 1) / rows;
     const int waves = segs * chunks;
     const dim3 grid((waves + 3) / 4), block(256);
@@ -285,9 +279,7 @@ static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, 
     ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     const int tstride = 64 * C - (THETA_LO + THETA_HI);
     const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
-    int rows = THETA_ROWS;
-    if (const char *e = getenv("FCPT_THETA_ROWS"))
-        rows = atoi(e) > 0 ? atoi(e) : rows;
+    const int rows = P.opt.theta_rows > 0 ? P.opt.theta_rows : THETA_ROWS;
     const int chunks = (P.nr + rows - 1) / rows;
     const int waves = chunks * tiles;
     const int nvb = (waves + 3) / 4;
@@ -311,30 +303,27 @@ bool transport_can_split(const Dev &P, bool shear_safe)
 {
     if (P.nphi < 256 || !shear_safe)
         return false;
-    const char *fb = getenv("FCPT_TRANSPORT_FALLBACK");
-    if (!fb || fb[0] != '0')
+    if (P.opt.transport_fallback != 0)
         return false; // the fallback kernels behind the fused one need all of its chunks in one launch
-    for (const char *name : {"FCPT_TRANSPORT_FUSED", "FCPT_TRANSPORT_ROWS"})
-        if (getenv(name))
-            return false; // tuning runs keep the one-launch form
-    if (const char *e = getenv("FCPT_TRANSPORT_SPLIT"))
-        if (e[0] == '0')
-            return false;
+    if (P.opt.transport_fused >= 0 || P.opt.transport_rows > 0)
+        return false; // tuning runs keep the one-launch form
+    if (P.opt.transport_split == 0)
+        return false;
     const int chunks = (P.nr + TF_ROWS - 1) / TF_ROWS, c_lo = (P.nr - 2 * FCPT_OVERLAP) / TF_ROWS;
     return c_lo >= 2 && c_lo < chunks;
 }
 // part: TRANSPORT_ALL, or -- for slabs with neighbours, when transport_can_split() -- launch_shift_means, then
 // TRANSPORT_INTERIOR on a side stream and TRANSPORT_EDGES (the chunks holding the rings a neighbour receives, rows
 // [7,14) and [nr-14,nr-7)) on the caller's stream, so that the ghost exchange runs under the interior chunks.
-TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hipStream_t st, int part)
+TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     // Transport, TransportEuler.cpp:112-136
     TransportResult res = {0, W.sigma, W.energy, W.vrad, W.vazi};
     // ---- everything in one kernel (tiled rings only) ------------------------------------------
     int CF = P.nphi >= 256 ? 1 : 0; // 1 cell per lane: 3 waves per SIMD (2 cells: 284 VGPRs, 1 wave)
-    if (const char *e = getenv("FCPT_TRANSPORT_FUSED")) { // 0: off, 1 / 2: cells per lane
-        const int v = atoi(e);
+    if (P.opt.transport_fused >= 0) { // 0: off, 1 / 2: cells per lane
+        const int v = P.opt.transport_fused;
         CF = v == 0 ? 0 : ((v == 1 || v == 2) && P.nphi >= 128 * v ? v : CF);
     }
     if (CF) {
@@ -345,9 +334,7 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
         Wm.vazi = P.vazi == W.vazi ? W.vazi_b : W.vazi;
         if (part == TRANSPORT_ALL)
             launch_shift_means(P, st); // else: the caller queued it ahead of both parts
-        int rows = TF_ROWS;
-        if (const char *e = getenv("FCPT_TRANSPORT_ROWS"))
-            rows = atoi(e) > 0 ? atoi(e) : rows;
+        const int rows = P.opt.transport_rows > 0 ? P.opt.transport_rows : TF_ROWS;
         const int tstride = 64 * CF - (CF == 2 ? TfHalo<2>::lo + TfHalo<2>::hi : TfHalo<1>::lo + TfHalo<1>::hi);
         const int tiles = (P.nphi + tstride - 1) / tstride;
         const int chunks = (P.nr + rows - 1) / rows;
@@ -357,10 +344,7 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
         // follows can change v_phi enough to break it in violent flows (the fuzzer found one: an ideal-gas
         // spreading ring), and the reference shifts by any amount.  FCPT_TRANSPORT_FALLBACK=0 drops the launches
         // for flows known to be benign; a violation is then reported as FCPT_ESHEAR.
-        (void)shear_safe;
-        int fallback = 1;
-        if (const char *e = getenv("FCPT_TRANSPORT_FALLBACK"))
-            fallback = e[0] != '0';
+        const int fallback = P.opt.transport_fallback != 0;
         TfChunks ch = {chunks, chunks, 0, 1};
         const int c_lo = (P.nr - 2 * FCPT_OVERLAP) / rows; // first chunk of the outer tail
         if (part == TRANSPORT_EDGES)
@@ -419,12 +403,9 @@ TransportResult launch_transport(const Dev &P, const Dev &W, bool shear_safe, hi
         }
     if (!C && P.nphi > 64 * 2)
         C = 2;
-    if (const char *e = getenv("FCPT_THETA_FUSED"))
-        if (e[0] == '0')
-            C = 0;
-    bool march = C != 0;
-    if (const char *e = getenv("FCPT_THETA_MARCH"))
-        march = march && e[0] != '0';
+    if (P.opt.theta_fused == 0)
+        C = 0;
+    const bool march = C != 0 && P.opt.theta_march != 0;
     if (march) {
         // the kernel reads the pre-transport v_phi and v_r of a ring (halo columns included) while other
         // wavefronts already store the new ones: never in place (the per-loop source step leaves its result in
@@ -479,11 +460,8 @@ bool cfl_by_rings(const Dev &P)
 {
     // one block per ring: mean and cells in one pass (even Nphi up to 1024 * CFL_MAXP = 8192; the isothermal
     // viscosity and sound speed per ring, or the lazily derived ones of the ideal EOS)
-    bool rings = (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 1024 * CFL_MAXP && (!P.adiabatic || P.lazy_derived) &&
-                 P.stabilize != 2;
-    if (const char *e = getenv("FCPT_CFL_RINGS"))
-        rings = rings && e[0] != '0';
-    return rings;
+    return (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 1024 * CFL_MAXP && (!P.adiabatic || P.lazy_derived) &&
+           P.stabilize != 2 && P.opt.cfl_rings != 0;
 }
 static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, hipStream_t st)
 {

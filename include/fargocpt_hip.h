@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FCPT_ABI_VERSION 3
+#define FCPT_ABI_VERSION 4
 
 /* error codes */
 #define FCPT_OK 0
@@ -35,6 +35,7 @@ extern "C" {
 #define FCPT_ESPLIT -4  /* slab too narrow: needs >= 2*FCPT_OVERLAP rings (src/split.cpp:42-47) */
 #define FCPT_ENODEV -5  /* no HIP device */
 #define FCPT_ESHEAR -6  /* a step ran beyond the FARGO shear limit without its fallback (see fcpt_step) */
+#define FCPT_ECOMM -7   /* an RCCL call failed, or librccl could not be loaded */
 
 /* src/constants.h:17-19 */
 #define FCPT_OVERLAP 7
@@ -89,7 +90,11 @@ enum {
      * FCPT_EINVAL otherwise */
     FCPT_F_VISC_CFAC_PHI = 16,
     FCPT_F_VISC_CFAC_R = 17,
-    FCPT_F_COUNT = 18
+    /* MASSFLOW (src/data.h), (Nr+1) x Nphi: the radial mass flux of the last Transport() through every
+     * interface, VanLeerRadial's "if (Q == &data[t_data::SIGMA])" branch (src/TransportEuler.cpp:579-615):
+     * mass per step, signed like v_r.  Materialised by the next fcpt_download(FCPT_F_MASSFLOW); not uploadable. */
+    FCPT_F_MASSFLOW = 18,
+    FCPT_F_COUNT = 19
 };
 
 /*
@@ -285,6 +290,17 @@ int fcpt_destroy(fcpt_ctx *ctx);
 int fcpt_set_stream(fcpt_ctx *ctx, void *hip_stream);
 int fcpt_synchronize(fcpt_ctx *ctx);
 
+/* Kernel-selection switches of one context, by name (lower case, e.g. "transport_fallback"): which of the
+ * parity-tested kernel variants the step uses, marching-chunk lengths, overlap of the ghost exchange.  The
+ * environment variables FCPT_<NAME> only provide the defaults read once in fcpt_create; no launch reads the
+ * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows,
+ * source_rows, theta_rows, transport_fallback, transport_split, fused_source, march_source, march_source_adi,
+ * theta_march, theta_fused, cfl_rings, cfl_split, source_ring_parts, fused_damping, comm_overlap, comm_loopback,
+ * graph_steps.
+ * FCPT_EINVAL for an unknown name.  (The reference has no counterpart: its variants are compile-time.) */
+int fcpt_set_option(fcpt_ctx *ctx, const char *name, int32_t value);
+int fcpt_get_option(const fcpt_ctx *ctx, const char *name, int32_t *value);
+
 int fcpt_get_split(const fcpt_ctx *ctx, fcpt_split *out);
 int fcpt_get_clock(const fcpt_ctx *ctx, fcpt_clock *out);
 int fcpt_set_clock(fcpt_ctx *ctx, const fcpt_clock *in);
@@ -351,7 +367,8 @@ int fcpt_cfl(fcpt_ctx *ctx, double *dt_local);
 /* Device-resident variants for multi-slab runs that keep dt off the host: fcpt_cfl_device
  * writes this slab's CFL minimum to *d_dt_local (a device address, e.g. of a tensor the
  * caller then MIN-all-reduces with RCCL on the same stream); fcpt_calculate_timestep_device
- * applies the CalculateTimeStep policy to the reduced value read from *d_cfl_global and
+ * applies the CalculateTimeStep policy to the reduced value read from *d_cfl_global (NULL: the value
+ * fcpt_cfl_allreduce left in the library's own device scalar) and
  * leaves the step length in the device clock, where fcpt_step_device / fcpt_post_device
  * pick it up.  No call in this group synchronises with the host. */
 int fcpt_cfl_device(fcpt_ctx *ctx, double *d_dt_local);
@@ -413,6 +430,34 @@ int fcpt_exchange_count(const fcpt_ctx *ctx, uint64_t *count);
 int fcpt_exchange_pack(fcpt_ctx *ctx, double *send_inner, double *send_outer);
 int fcpt_exchange_unpack(fcpt_ctx *ctx, const double *recv_inner, const double *recv_outer);
 
+/* ---- radial slabs on several GPUs: RCCL inside the library ------------------------------------------
+ * The reference's two communication points, on the context's stream (no host synchronisation, no stream hop):
+ * CommunicateBoundaries' MPI_Isend/MPI_Irecv with CPU_Prev/CPU_Next (src/commbound.cpp:130-158) become one
+ * group of ncclSend/ncclRecv with slab rank-1 / rank+1 over xGMI, condition_cfl's MPI_Allreduce(MPI_MIN)
+ * (src/cfl.cpp:379) an ncclAllReduce(ncclMin) of one device double.  One process (or thread) per GPU, as one
+ * MPI rank per slab in the reference (src/parallel.cpp:28-40).
+ *
+ * Bootstrap = ncclGetUniqueId on slab 0, the 128 bytes handed to every slab by the host's own means (the
+ * reference's host would MPI_Bcast them; bench.py uses its torch.distributed store, the C++ driver a file),
+ * then fcpt_comm_init on every slab (collective: ncclCommInitRank with rank = d->rank of d->nranks, on the
+ * device the context was created on).  librccl is bound at run time; single-GPU users never load it. */
+#define FCPT_COMM_ID_BYTES 128
+int fcpt_comm_unique_id(void *id128);
+int fcpt_comm_init(fcpt_ctx *ctx, const void *id128);
+int fcpt_comm_destroy(fcpt_ctx *ctx);
+
+/* CommunicateBoundaries (src/commbound.cpp:98-182) of this slab, whole: pack rows [7,14) / [nr-14,nr-7),
+ * grouped send/recv with the neighbours, unpack into rows [0,7) / [nr-7,nr).  Asynchronous.  With the option
+ * comm_overlap the transfers run on the library's communication stream while the CFL terms of the interior
+ * rings (fcpt_cfl_begin) are evaluated on the context's stream. */
+int fcpt_exchange(fcpt_ctx *ctx);
+
+/* condition_cfl's MPI_Allreduce (src/cfl.cpp:379), device-resident: queues the local reduction
+ * (src/cfl.cpp:185-376) and the MIN over all slabs; the result stays in device memory, where
+ * fcpt_calculate_timestep_device(ctx, NULL) picks it up.  With dt_global != NULL the call blocks and also
+ * returns the value.  fcpt_run_steps uses both calls when the context has a communicator. */
+int fcpt_cfl_allreduce(fcpt_ctx *ctx, double *dt_global);
+
 /* The rest of step_Euler after CommunicateBoundaries (src/simulation.cpp:244-265):
  * apply_boundary_condition(final=true) (damping first) and
  * recalculate_derived_disk_quantities.  Asynchronous. */
@@ -424,9 +469,9 @@ int fcpt_post(fcpt_ctx *ctx, double dt);
  * calls it once more before the loop, src/simulation.cpp:463.) */
 int fcpt_apply_boundary(fcpt_ctx *ctx, double dt, int32_t final);
 
-/* Convenience for single-slab runs: K iterations of
- * {cfl, calculate_timestep, [snap], step, post} without returning to the caller,
- * as sim::run does (src/simulation.cpp:515-553).  If `snap` is non-zero the
+/* K iterations of {cfl [+ MIN over the slabs], calculate_timestep, [snap], step, [exchange], post} without
+ * returning to the caller, as sim::run does (src/simulation.cpp:515-553).  A context with a communicator
+ * (fcpt_comm_init) runs the multi-slab loop: every slab's host calls this with the same arguments.  If `snap` is non-zero the
  * step is snapped to monitor times and n_monitor advances.  nsteps_done may be
  * NULL.  Stops early when time reaches t_final = nsnapshots*nmonitor*monitor_timestep
  * unless t_final <= 0. */

@@ -76,3 +76,76 @@ def test_two_hip_slabs_over_torch_distributed(tmp_path, product, adiabatic):
         # the reference itself agrees to 4e-13 between 1 and 2 ranks
         assert rel_err(got[k], ref[k]) <= 1e-12, k
     ctx.close()
+
+
+# ---- RCCL inside the library (fcpt_comm_init / fcpt_exchange / fcpt_cfl_allreduce / fcpt_run_steps) ----------
+# One GPU cannot hold two RCCL ranks, so the transfer itself is rehearsed with a communicator of one rank whose
+# slab is its own neighbour on both sides (option comm_loopback): rows [7,14) arrive in rows [0,7) and rows
+# [nr-14,nr-7) in rows [nr-7,nr), through ncclSend/ncclRecv on the context's stream.
+
+def _middle_slab(product, adiabatic, loopback):
+    import torch  # the HIP runtime torch bundles first
+    from fargocpt_amd import driver, setups
+    d = setups.planet_disk(product, 3 * 40, 320, adiabatic=adiabatic)
+    d.rank, d.nranks = 1, 3
+    radii = product.radii(d)
+    fields = product.initial_fields(d.copy(), radii)
+    from tests.util import perturb
+    fields = perturb(fields, d, 1e-3)
+    ctx = driver.make_context(product, d, fields=fields, radii=radii, bodies=setups.jupiter_bodies(d))
+    if loopback:
+        ctx.set_option("comm_loopback", 1)
+        ctx.comm_init(product.comm_unique_id())
+    return ctx
+
+
+def _host_loopback_exchange(ctx):
+    cnt = ctx.exchange_count()
+    s_in, s_out = np.zeros(cnt), np.zeros(cnt)
+    ctx.exchange_pack(s_in, s_out)
+    ctx.synchronize()
+    ctx.exchange_unpack(s_in, s_out)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("adiabatic,overlap", [(False, 0), (False, 1), (True, 0), (True, 1)])
+def test_library_rccl_exchange_and_loop(product, adiabatic, overlap):
+    """fcpt_exchange + fcpt_cfl_allreduce + the multi-slab fcpt_run_steps against the same sequence driven from the
+    host with host-staged ghost rings: identical bits (state, clock), with and without the transfers overlapping
+    the interior CFL."""
+    nsteps = 8
+    a = _middle_slab(product, adiabatic, loopback=True)
+    a.set_option("comm_overlap", overlap)
+    assert a.get_option("comm_overlap") == overlap
+    b = _middle_slab(product, adiabatic, loopback=False)
+    # sim::init's sequence
+    for ctx, xchg in ((a, a.exchange), (b, lambda: _host_loopback_exchange(b))):
+        ctx.calculate_timestep(ctx.cfl_allreduce() if ctx is a else ctx.cfl())
+        xchg()
+        ctx.apply_boundary(0.0, False)
+        ctx.calculate_timestep(ctx.cfl_allreduce() if ctx is a else ctx.cfl())
+        xchg()
+    assert a.run_steps(nsteps) == nsteps
+    for _ in range(nsteps):
+        dt = b.calculate_timestep(b.cfl())
+        b.step(dt)
+        _host_loopback_exchange(b)
+        b.post(dt)
+    ca, cb = a.clock, b.clock
+    assert (ca.time, ca.last_dt, ca.n_hydro_iter) == (cb.time, cb.last_dt, cb.n_hydro_iter)
+    sa, sb = a.state(), b.state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.comm_destroy()
+    a.close()
+    b.close()
+
+
+def test_library_comm_errors(product):
+    from fargocpt_amd import binding as B
+    ctx = _middle_slab(product, False, loopback=False)
+    with pytest.raises(B.FcptError, match="fcpt_comm_init"):
+        ctx.exchange()
+    with pytest.raises(B.FcptError, match="unknown option"):
+        ctx.set_option("no_such_switch", 1)
+    ctx.close()

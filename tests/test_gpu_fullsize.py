@@ -1,5 +1,9 @@
-"""BASELINE.json's full sizes (2048 x 4096 and the 2048 x 6144 slab split), where the oracle is too slow
-to be the checker: size-independent properties of the path.
+"""BASELINE.json's full sizes (512 x 1536, 1024 x 3072, 2048 x 6144 in four slabs, 4096 x 4 and the headline
+2048 x 4096).  Two kinds of checks:
+
+1. HIP against the oracle, field by field (1e-10, dt histories 1e-9), over a handful of steps: the oracle does
+   35-46 M cell-updates/s on the GPU box's host cores, i.e. a few seconds per case (tests `*_against_oracle`);
+2. size-independent properties of the path over more steps than the oracle is worth waiting for:
 
 * azimuthal symmetry: an axisymmetric disk without planet stays axisymmetric to rounding -- every
   wavefront tile seam of the marching kernels and every integer shift of the FARGO transport would
@@ -16,10 +20,53 @@ import numpy as np
 import pytest
 
 from fargocpt_amd import binding as B, driver, setups
-from tests.util import perturb, rel_err
+from tests.util import perturb, rel_err, run_pair
 
 pytestmark = pytest.mark.gpu
 NR, NPHI = 2048, 4096
+TOL, TOL_DT = 1e-10, 1e-9
+
+
+def _check_pair(res, fields):
+    (sa, dta), (sb, dtb) = res
+    assert np.allclose(dta, dtb, rtol=TOL_DT, atol=0), (dta, dtb)
+    errs = {k: rel_err(sa[k], sb[k]) for k in fields}
+    assert all(np.isfinite(sa[k]).all() for k in fields)
+    assert max(errs.values()) <= TOL, errs
+    return errs
+
+
+# BASELINE.json configs 2, 3, 4 and the headline workload at their own sizes: (name, nr, nphi, ideal EOS, HIP slabs, steps)
+FULL_CASES = [
+    ("config2_512x1536", 512, 1536, False, 1, 10),
+    ("config3_1024x3072_ideal", 1024, 3072, True, 1, 8),
+    ("config4_2048x6144_4slabs", 2048, 6144, False, 4, 5),
+    ("headline_2048x4096", 2048, 4096, False, 1, 6),
+    ("headline_2048x4096_ideal", 2048, 4096, True, 1, 5),
+]
+
+
+@pytest.mark.parametrize("name,nr,nphi,adiabatic,nslabs,nsteps", FULL_CASES, ids=[c[0] for c in FULL_CASES])
+def test_full_size_against_oracle(product, oracle, name, nr, nphi, adiabatic, nslabs, nsteps):
+    """The BASELINE configurations at full size, HIP (in `nslabs` radial slabs) against the single-slab oracle."""
+    d = setups.planet_disk(product, nr, nphi, adiabatic=adiabatic)
+    fields = ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ())
+    _check_pair(run_pair(product, oracle, d, nsteps, bodies=setups.jupiter_bodies(d), nslabs=(nslabs, 1)), fields)
+
+
+# (configs 1 and 5 -- 128 x 384 and 4096 x 4 -- run at their BASELINE sizes in tests/test_gpu_parity.py)
+
+
+@pytest.mark.parametrize("adiabatic", [False, True])
+def test_fallback_transport_at_full_size_against_oracle(product, oracle, adiabatic):
+    """A step of 4x the CFL time step at 2048 x 4096: k_transport_fused meets |Nshift[i] - Nshift[i-1]| > 1 and
+    hands over to the two-kernel transport queued behind it, whose grid is capped at 256 blocks with a grid-stride
+    loop -- the form that only differs from the small-grid one above 256 virtual blocks."""
+    d = setups.planet_disk(product, NR, NPHI, adiabatic=adiabatic)
+    d.damping = 0
+    d.first_dt = 1.0  # no 1.1x ramp: the first step already runs at the CFL limit
+    fields = ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ())
+    _check_pair(run_pair(product, oracle, d, 3, bodies=setups.jupiter_bodies(d), dt_scale=4.0), fields)
 
 
 def _run(lib, d, fields, radii, nsteps, bodies=None, nslabs=1, device_loop=False):

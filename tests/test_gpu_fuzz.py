@@ -92,16 +92,46 @@ def draw(lib, seed):
     return d, nslabs, planet
 
 
+GROWTH_CAP = 1.0e4   # widened bar at most 1e-13 x 1e4 = 1e-9; a more violent draw is compared over fewer steps instead
+RELAXED = []         # (test, seed, steps, growth, tolerance): every draw that did not meet the plain 1e-10 bar
+COMPARED = []        # every draw that was compared at all
+
+
 def _tolerance(oracle_run, b, fields, worst):
     """1e-10, unless the draw is an unstable flow that amplifies rounding by orders of magnitude per step: then
     what the oracle does to cell-wise 1e-15 relative noise on its own input over the same steps (measured only
-    when the plain bar is missed)."""
+    when the plain bar is missed), never more than GROWTH_CAP."""
     if worst <= TOL:
         return TOL, 1.0
     noise = 1.0e-15
     b2 = oracle_run(noise)
     growth = max(rel_err(b2[k], b[k]) for k in fields) / noise
-    return max(TOL, 1.0e-13 * growth), growth   # the two paths differ by a few 1e-14 before any amplification; one noise realisation
+    # the two paths differ by a few 1e-14 before any amplification; one noise realisation
+    return max(TOL, 1.0e-13 * min(growth, GROWTH_CAP)), growth
+
+
+def _judge(test, seed, attempt):
+    """attempt(nsteps) -> None (draw unusable) | (errs, dterr, tol, growth).  10 steps; a draw whose flow amplifies
+    rounding beyond GROWTH_CAP in ten steps is compared after 3 instead, and skipped (and listed) if even that is
+    beyond the cap -- never passed on a bar wider than 1e-9."""
+    for nsteps in (10, 3):
+        res = attempt(nsteps)
+        if res is None:
+            return
+        errs, dterr, tol, growth = res
+        if growth <= GROWTH_CAP:
+            break
+    else:
+        RELAXED.append((test, seed, nsteps, growth, None))
+        pytest.skip(f"seed {seed}: the oracle amplifies 1e-15 noise by {growth:.1e} in 3 steps: not a usable draw")
+    COMPARED.append((test, seed))
+    if tol > TOL:
+        RELAXED.append((test, seed, nsteps, growth, tol))
+        print(f"[fuzz] {test} seed {seed}: relaxed bar {tol:.1e} over {nsteps} steps (growth {growth:.1e}), "
+              f"errors {max(errs.values()):.2e}, dt {dterr:.2e}")
+    assert dterr <= 10 * tol, f"seed {seed}: time-step history differs by {dterr:.3e} (growth {growth:.1e}, {nsteps} steps)"
+    for k, e in errs.items():
+        assert e <= tol, f"seed {seed}: {k}: {e:.3e} (tolerance {tol:.1e}, growth {growth:.1e}, {nsteps} steps)"
 
 
 @pytest.mark.parametrize("seed", range(FIRST, FIRST + NSEEDS))
@@ -109,27 +139,29 @@ def test_random_configuration(product, oracle, seed):
     d, nslabs, planet = draw(product, seed)
     bodies = setups.jupiter_bodies(d) if planet else None
     adiabatic = d.eos == B.EOS_IDEAL
-    try:
-        b, dtb = run_pair(oracle, oracle, d, 10, bodies=bodies, nslabs=(1, 0), **_EXTRA)[0]
-    except B.FcptError as err:   # a draw outside the supported space (e.g. NaN radii of a coarse exponential grid):
-        assert "FCPT_EINVAL" in str(err)          # both libraries must refuse it the same way
-        with pytest.raises(B.FcptError, match="FCPT_EINVAL"):
-            run_pair(product, product, d, 1, bodies=bodies, nslabs=(1, 0))
-        return
-    a, dta = run_pair(product, product, d, 10, bodies=bodies, nslabs=(nslabs, 0), **_EXTRA)[0]
-    if not all(np.isfinite(b[k]).all() for k in b):
-        pytest.skip("the oracle itself left the finite range: not a usable draw")
     fields = ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ())
-    if WIDE:   # every kernel reduces in a fixed order: a second run must give the same bits (a race would not)
-        a2, dta2 = run_pair(product, product, d, 10, bodies=bodies, nslabs=(nslabs, 0), **_EXTRA)[0]
-        assert dta2 == dta and all(np.array_equal(a2[k], a[k], equal_nan=True) for k in fields), f"seed {seed}: run-to-run difference"
-    errs = {k: rel_err(a[k], b[k]) for k in fields}
-    dterr = max(abs(x - y) / y for x, y in zip(dta, dtb))
-    tol, growth = _tolerance(lambda noise: run_pair(oracle, oracle, d, 10, bodies=bodies, nslabs=(1, 0), noise=noise, **_EXTRA)[0][0],
-                             b, fields, max(max(errs.values()), 0.1 * dterr))
-    assert dterr <= 10 * tol, f"seed {seed}: time-step history differs by {dterr:.3e} (growth {growth:.1e})"
-    for k in fields:
-        assert errs[k] <= tol, f"seed {seed}: {k}: {errs[k]:.3e} (tolerance {tol:.1e}, growth {growth:.1e})"
+
+    def attempt(nsteps):
+        try:
+            b, dtb = run_pair(oracle, oracle, d, nsteps, bodies=bodies, nslabs=(1, 0), **_EXTRA)[0]
+        except B.FcptError as err:   # a draw outside the supported space (e.g. NaN radii of a coarse exponential grid):
+            assert "FCPT_EINVAL" in str(err)          # both libraries must refuse it the same way
+            with pytest.raises(B.FcptError, match="FCPT_EINVAL"):
+                run_pair(product, product, d, 1, bodies=bodies, nslabs=(1, 0))
+            return None
+        a, dta = run_pair(product, product, d, nsteps, bodies=bodies, nslabs=(nslabs, 0), **_EXTRA)[0]
+        if not all(np.isfinite(b[k]).all() for k in b):
+            pytest.skip("the oracle itself left the finite range: not a usable draw")
+        if WIDE:   # every kernel reduces in a fixed order: a second run must give the same bits (a race would not)
+            a2, dta2 = run_pair(product, product, d, nsteps, bodies=bodies, nslabs=(nslabs, 0), **_EXTRA)[0]
+            assert dta2 == dta and all(np.array_equal(a2[k], a[k], equal_nan=True) for k in fields), f"seed {seed}: run-to-run difference"
+        errs = {k: rel_err(a[k], b[k]) for k in fields}
+        dterr = max(abs(x - y) / y for x, y in zip(dta, dtb))
+        tol, growth = _tolerance(lambda noise: run_pair(oracle, oracle, d, nsteps, bodies=bodies, nslabs=(1, 0), noise=noise, **_EXTRA)[0][0],
+                                 b, fields, max(max(errs.values()), 0.1 * dterr))
+        return errs, dterr, tol, growth
+
+    _judge("host_loop", seed, attempt)
 
 
 def _device_loop(lib, d, bodies, nsteps, noise=0.0):
@@ -155,28 +187,31 @@ def _device_loop(lib, d, bodies, nsteps, noise=0.0):
 @pytest.mark.parametrize("seed", range(FIRST, FIRST + NSEEDS, 2))
 def test_random_configuration_device_loop(product, oracle, seed):
     """The same draws through fcpt_run_steps: dt from the CFL kernels to the policy kernel to the step without
-    leaving the device, the transport without its fallback launches (CFL <= 0.8) and with the ring sums the
-    source march leaves behind -- the path bench.py times."""
+    leaving the device, the fused transport with its fallback launches queued behind it and with the ring sums
+    the source march leaves behind -- the path bench.py times."""
     d, _, planet = draw(product, seed)
     bodies = setups.jupiter_bodies(d) if planet else None
-    try:
-        b = _device_loop(oracle, d, bodies, 12)
-    except B.FcptError as err:
-        assert "FCPT_EINVAL" in str(err)
-        return
-    if not all(np.isfinite(v).all() for v in b.values()):
-        pytest.skip("the oracle itself left the finite range: not a usable draw")
-    a = _device_loop(product, d, bodies, 12)
     fields = ("sigma", "vrad", "vazi") + (("energy",) if d.eos == B.EOS_IDEAL else ())
-    if WIDE:
-        a2 = _device_loop(product, d, bodies, 12)
-        assert a2["time"] == a["time"] and all(np.array_equal(a2[k], a[k], equal_nan=True) for k in fields), f"seed {seed}: run-to-run difference"
-    errs = {k: rel_err(a[k], b[k]) for k in fields}
-    terr = abs(a["time"] - b["time"]) / abs(b["time"])
-    tol, growth = _tolerance(lambda noise: _device_loop(oracle, d, bodies, 12, noise), b, fields, max(max(errs.values()), 0.1 * terr))
-    assert terr <= 10 * tol, f"seed {seed}: time differs by {terr:.3e} (growth {growth:.1e})"
-    for k in fields:
-        assert errs[k] <= tol, f"seed {seed}: {k}: {errs[k]:.3e} (tolerance {tol:.1e}, growth {growth:.1e})"
+
+    def attempt(nsteps):
+        nsteps = nsteps + 2
+        try:
+            b = _device_loop(oracle, d, bodies, nsteps)
+        except B.FcptError as err:
+            assert "FCPT_EINVAL" in str(err)
+            return None
+        if not all(np.isfinite(v).all() for v in b.values()):
+            pytest.skip("the oracle itself left the finite range: not a usable draw")
+        a = _device_loop(product, d, bodies, nsteps)
+        if WIDE:
+            a2 = _device_loop(product, d, bodies, nsteps)
+            assert a2["time"] == a["time"] and all(np.array_equal(a2[k], a[k], equal_nan=True) for k in fields), f"seed {seed}: run-to-run difference"
+        errs = {k: rel_err(a[k], b[k]) for k in fields}
+        terr = abs(a["time"] - b["time"]) / abs(b["time"])
+        tol, growth = _tolerance(lambda noise: _device_loop(oracle, d, bodies, nsteps, noise), b, fields, max(max(errs.values()), 0.1 * terr))
+        return errs, terr, tol, growth
+
+    _judge("device_loop", seed, attempt)
 
 
 @pytest.mark.parametrize("seed", range(FIRST, FIRST + max(40, NSEEDS // 4)))
@@ -249,3 +284,21 @@ def test_random_slab_overlap_paths(product, seed, monkeypatch):
     for pa, pb in zip(got[0][2], got[1][2]):
         for x, y in zip(pa, pb):
             assert (x is None and y is None) or np.array_equal(x, y, equal_nan=True)
+
+
+def test_zz_share_of_relaxed_draws():
+    """Runs last: the draws that did not meet the plain 1e-10 bar stay a small, listed minority (each of them was
+    held to at most 1e-9, over ten or three steps)."""
+    import json
+    import os
+    if not COMPARED:
+        pytest.skip("no draws compared in this session")
+    rec = {"compared": len(COMPARED), "relaxed": [dict(test=t, seed=sd, steps=n, growth=g, tolerance=tol)
+                                                   for t, sd, n, g, tol in RELAXED], "growth_cap": GROWTH_CAP}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "fuzz_relaxed.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+    print(f"[fuzz] {len(RELAXED)} of {len(COMPARED)} compared draws needed a relaxed bar or fewer steps: "
+          f"{[(t, sd) for t, sd, *_ in RELAXED]}")
+    assert len(RELAXED) <= max(2, 0.15 * len(COMPARED)), rec

@@ -240,8 +240,8 @@ def test_transport_beyond_shear_limit_falls_back(product, oracle, monkeypatch):
     """k_transport_fused couples rings i-1 and i through one lane shift, which covers
     |Nshift[i] - Nshift[i-1]| <= 1 (every dt inside the FARGO shear limit, cfl.cpp:207-220).  A step
     of 4x the CFL time step breaks that: the kernel must give up and the unfused kernels queued
-    behind it must produce the step.  (Steps whose dt is the CFL policy's with CFL <= 0.8 cannot get
-    there and skip the two idle launches.)"""
+    behind it must produce the step.  (They are queued behind every fused launch: the CFL policy's dt does
+    not rule the situation out when the source step itself changes v_phi violently.)"""
     d = setups.planet_disk(product, 48, 512)
     d.damping = 0
     d.first_dt = 1.0  # no 1.1x ramp: the first step already runs at the CFL limit
