@@ -82,6 +82,7 @@ class Desc(C.Structure):
         ("profile_cutoff_inner", _i32), ("profile_cutoff_outer", _i32),
         ("profile_cutoff_point_inner", _f64), ("profile_cutoff_width_inner", _f64),
         ("profile_cutoff_point_outer", _f64), ("profile_cutoff_width_outer", _f64),
+        ("write_massflow", _i32), ("_pad5", _i32),
     ]
 
     def copy(self) -> "Desc":

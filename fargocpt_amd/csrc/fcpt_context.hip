@@ -48,7 +48,6 @@ struct fcpt_ctx {
     bool stepped = false; // fcpt_step ran since the last fcpt_post
     bool cfl_interior = false; // fcpt_cfl_begin evaluated the interior rings of the current state
     bool damp_any = false;     // this slab holds rings of a damping zone
-    bool massflow_valid = false; // the MASSFLOW grid holds the flux of the last Transport()
     bool damp_foldable = false; // ... and its damping can be folded into the transport (no "mean" target, Euler)
     // fcpt_step_device_begin: the interior chunks of the transport run on `side` while the caller's stream
     // marches the chunks with the neighbours' ghost rings, packs and sends them
@@ -388,6 +387,7 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool spl
     apply_boundary_view(c, Q, false);
     if (frog)
         launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step (saved in cfl_dt)
+    launch_massflow(Q, st); // WriteMassFlow: what this Transport() carries through the interfaces
     TransportResult tr;
     if (split && !frog && transport_can_split(Q, shear_safe) && c->side) {
         launch_shift_means(Q, st);
@@ -723,6 +723,9 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     if (P.stabilize) {
         AL(cfac_phi, ns) AL(cfac_r, ns)
     }
+    if (d->write_massflow) {
+        AL(massflow, nv)
+    }
 #undef AL
     if (!rc && hipHostMalloc((void **)&c->h_clk, sizeof(DevClock)) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -753,6 +756,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     c->grid[FCPT_F_QMINUS] = P.qminus;
     c->grid[FCPT_F_VISC_CFAC_PHI] = P.cfac_phi; // null unless StabilizeViscosity
     c->grid[FCPT_F_VISC_CFAC_R] = P.cfac_r;
+    c->grid[FCPT_F_MASSFLOW] = P.massflow; // null unless WriteMassFlow
 
     P.zero_no_ghost = c->s.zero_no_ghost;
     P.one_no_ghost_vr = c->s.one_no_ghost_vr;
@@ -1022,7 +1026,7 @@ int fcpt_set_clock(fcpt_ctx *c, const fcpt_clock *in)
 
 static size_t grid_count(const fcpt_ctx *c, int32_t f)
 {
-    const bool vec = f == FCPT_F_VRAD || f == FCPT_F_VRAD0;
+    const bool vec = f == FCPT_F_VRAD || f == FCPT_F_VRAD0 || f == FCPT_F_MASSFLOW;
     return (size_t)(c->s.nr + (vec ? 1 : 0)) * c->d.nphi;
 }
 
@@ -1042,7 +1046,6 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
         c->pressure_valid = false;
         c->potential_valid = false;
         c->stepped = false;
-        c->massflow_valid = false;
     }
     if (f == FCPT_F_SCALE_HEIGHT)
         c->potential_valid = false;

@@ -174,6 +174,7 @@ struct Dev {
     double *qr, *qphi, *divv, *trr, *tpp, *trp /* (nr+1) rows */, *qplus, *qminus;
     // StabilizeViscosity (viscosity.cpp:256-348): correction factors c1_phi, c1_r; null when it is 0
     double *cfac_phi, *cfac_r;
+    double *massflow; // MASSFLOW (data.h:76), (nr+1) rows; null without WriteMassFlow
     CArr g_ra3;    // pow(Rinf[i], 3)
     int stabilize; // 0: off, 1: damp the viscous velocity update, 2: limit the time step
     // transport: momenta / density / energy, two sets (A: after pass 1, B: radial + final)

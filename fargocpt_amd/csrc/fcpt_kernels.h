@@ -15,7 +15,7 @@ enum KernelId {
     KID_VISC_VR, KID_QPLUS, KID_SUBSTEP3, KID_BOUNDARY, KID_DAMPING, KID_TRANSPORT_RADIAL,
     KID_RING_MEAN, KID_THETA1, KID_THETA2, KID_VELOCITIES, KID_CFL_INIT, KID_CFL_CELLS, KID_CLOCK,
     KID_SRC_FUSED, KID_AV_FUSED, KID_VISC_FUSED, KID_SOURCE_MARCH, KID_THETA_FUSED, KID_THETA_MARCH,
-    KID_TRANSPORT_FUSED, KID_COUNT
+    KID_TRANSPORT_FUSED, KID_MASSFLOW, KID_COUNT
 };
 extern const char *const kKernelNames[KID_COUNT];
 
@@ -58,6 +58,7 @@ enum { TRANSPORT_ALL = 0, TRANSPORT_EDGES = 1, TRANSPORT_INTERIOR = 2 };
 TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part = TRANSPORT_ALL);
 bool transport_can_split(const Dev &P, bool shear_safe);
 void launch_shift_means(const Dev &P, hipStream_t st);
+void launch_massflow(const Dev &P, hipStream_t st);
 void launch_substep3_cooling_only(const Dev &P, hipStream_t st);
 void launch_disk_on_body(const Dev &P, double x, double y, double r_object, double smoothing_fixed, double r_sm, double *out,
                          hipStream_t st);

@@ -331,6 +331,7 @@ void config_to_desc(const Config &c, fcpt_desc &d)
     d.damping_outer_limit = num(c, "DampingOuterLimit", 0.95);
     d.damping_time_factor = num(c, "DampingTimeFactor", 1.0);
     d.damping_time_radius_outer = num(c, "DampingTimeRadiusOuter", d.rmax, K_LEN);
+    d.write_massflow = c.flag("WriteMassFlow", false) ? 1 : 0; // parameters.cpp:345
     // hydro centre = the first body (HydroFrameCenter: primary)
     if (!c.nbody.empty() && c.nbody[0].count("mass"))
         d.hydro_center_mass = number(c.nbody[0].at("mass"), K_MASS);
@@ -656,6 +657,29 @@ int main(int argc, char **argv)
             // the CFL condition of the next step reads Q+ and Q- of the last one (cfl.cpp:303-316): restart.cpp:78-95
             write_grid(ctx, FCPT_F_QPLUS, ns, dir + "Qplus.dat");
             write_grid(ctx, FCPT_F_QMINUS, ns, dir + "Qminus.dat");
+        }
+        if (d.write_massflow && !name) {
+            // MassFlow1D.dat (t_polargrid::write1D, polargrid.cpp:187-278, of a vector grid that is integrated over
+            // azimuth): pairs (Rinf[n], sum_j MASSFLOW(n, j) / (Nmonitor MonitorTimestep)) -- calculate_massflow,
+            // quantities.cpp:770-781 -- then the grid is cleared (data.cpp:277)
+            std::vector<double> mf(nv), out(2 * (size_t)(d.nr_global + 1));
+            CHECK(fcpt_download(ctx, FCPT_F_MASSFLOW, mf.data()));
+            const double denom = (double)d.nmonitor * d.monitor_timestep;
+            for (int n = 0; n <= d.nr_global; ++n) {
+                double sum = 0.0;
+                for (int j = 0; j < d.nphi; ++j)
+                    sum += mf[(size_t)n * d.nphi + j] / denom;
+                out[2 * n] = radii[n];
+                out[2 * n + 1] = sum;
+            }
+            FILE *f1 = fopen((dir + "MassFlow1D.dat").c_str(), "wb");
+            if (!f1 || fwrite(out.data(), sizeof(double), out.size(), f1) != out.size()) {
+                fprintf(stderr, "fargocpt_hip: cannot write %sMassFlow1D.dat\n", dir.c_str());
+                exit(1);
+            }
+            fclose(f1);
+            std::fill(mf.begin(), mf.end(), 0.0);
+            CHECK(fcpt_upload(ctx, FCPT_F_MASSFLOW, mf.data()));
         }
         misc_entry misc;
         memset(&misc, 0, sizeof(misc));

@@ -10,7 +10,7 @@ const char *const kKernelNames[KID_COUNT] = {
     "k_visc_vr", "k_qplus_qminus", "k_substep3", "k_boundary", "k_damping", "k_transport_radial",
     "k_ring_mean", "k_transport_theta1", "k_transport_theta2", "k_velocities", "k_cfl_final",
     "k_cfl_cells", "k_clock", "k_src_fused", "k_av_fused", "k_visc_fused", "k_source_march",
-    "k_transport_theta_fused", "k_transport_theta_march", "k_transport_fused"};
+    "k_transport_theta_fused", "k_transport_theta_march", "k_transport_fused", "k_massflow"};
 
 thread_local Profiler *g_prof = nullptr;
 
@@ -251,6 +251,11 @@ static void launch_radial(const Dev &P, const int *only_if, hipStream_t st)
         KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<true>, grid, l.block, P, only_if, gx, gy);
     else
         KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, grid, l.block, P, only_if, gx, gy);
+}
+void launch_massflow(const Dev &P, hipStream_t st)
+{
+    if (P.massflow)
+        LAUNCH2D(KID_MASSFLOW, k_massflow, P.nr - 1, P);
 }
 void launch_shift_means(const Dev &P, hipStream_t st)
 {

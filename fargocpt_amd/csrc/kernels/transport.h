@@ -61,6 +61,24 @@ __device__ __forceinline__ double star_radial(const Dev &P, const StarGeo &g, do
     return x1 + dist * 0.5 * dq;
 }
 
+// WriteMassFlow: the mass VanLeerRadial carries through the inner interface of every cell, accumulated in the
+// MASSFLOW grid (TransportEuler.cpp:566-571,609-616).  For the density QRStar is Sigma / Sigma = 1 on every open
+// interface (0 on row 0, unset on row Nr), so varq_inf = dt dphi Rinf[i] DensityStar v_r and the reference's extra
+// "+= varq_sup" of the last ring adds nothing.  A monitoring quantity: its own small kernel ahead of the
+// transport (same Sigma, same post-kick v_r, same dt), so that the marching kernels stay as they are.
+template <bool ROWU> __global__ void k_massflow(const Dev P)
+{
+    CELL(1, P.nr - 1);
+    const double dt = P.clk->dt;
+    const double v = P.vrad[IDX(i, j)];
+    const StarGeo geo = star_geo(P, i);
+    const double wm2 = i >= 2 ? P.sigma[IDX(i - 2, j)] : 0.0, wm1 = P.sigma[IDX(i - 1, j)];
+    const double w0 = P.sigma[IDX(i, j)], wp1 = i + 1 < P.nr ? P.sigma[IDX(i + 1, j)] : 0.0;
+    const double rho = star_radial(P, geo, v, dt, wm2, wm1, w0, wp1);
+    const double g = dt * P.dphi * P.Rinf[i];
+    P.massflow[IDX(i, j)] += g * 1.0 * rho * v;
+}
+
 // compute_momenta_from_velocities (:471-493) + OneWindRad (:138-167) with all
 // VanLeerRadial calls (:545-620) in one pass.  Reads Sigma, v_r, v_phi(, e) and
 // writes the transported momenta / density / energy to set B, so the in-place

@@ -197,3 +197,42 @@ def jupiter_bodies(d: B.Desc):
     y = [0.0, 0.0]
     m = [d.hydro_center_mass, M_JUP]
     return x, y, m
+
+
+def steady_state_accretion(lib: B.Library, nr=198, nphi=1) -> B.Desc:
+    """test/steady_state_accretion/setup.yml: an alpha disk (alpha = 0.1, h = 0.005) with Sigma ~ r^-1/2 is a
+    steady accretion flow of 3 pi Sigma nu = 1e-8 solMass/yr; outflow boundaries, Sigma and v_r damped to the
+    initial profile near both edges, 198 x 1 cells on r in [10, 100] au, WriteMassFlow."""
+    d = lib.desc_default()
+    d.nr_global, d.nphi = nr, nphi
+    d.rmin, d.rmax, d.radial_spacing = 10.0, 100.0, B.SPACING_LOGARITHMIC
+    d.ic = B.IC_PROFILE
+    d.sigma0 = 600.187 / SIGMA_CGS
+    d.sigma_slope, d.sigma_floor = 0.5, 1e-8
+    d.aspect_ratio, d.flaring_index = 0.005, 0.0
+    d.viscous_alpha, d.constant_viscosity = 0.1, 0.0
+    d.artificial_viscosity, d.artificial_viscosity_dissipation = B.ARTVISC_NONE, 1
+    d.artificial_viscosity_factor = 1.41
+    d.eos, d.adiabatic_index, d.mu = B.EOS_ISOTHERMAL, 1.4, 2.35
+    d.heating_viscous = 0
+    d.minimum_temperature, d.maximum_temperature = 3.0 / TEMP0_K, 1e100 / TEMP0_K
+    d.cfl = 0.4
+    d.thickness_smoothing = 0.0
+    d.fast_transport = 1
+    d.omega_frame = 0.0
+    _composite(d, 0, "outflow")
+    _composite(d, 1, "outflow")
+    d.damping = 1
+    d.damping_inner_limit, d.damping_outer_limit = 2.0, 0.64
+    d.damping_time_factor, d.damping_time_radius_outer = 1.0e-2, d.rmax
+    for arr in (d.damp_vaz, d.damp_energy):
+        arr[0] = arr[1] = B.DAMP_NONE
+    for arr in (d.damp_vrad, d.damp_sigma):
+        arr[0] = arr[1] = B.DAMP_REFERENCE
+    d.nsnapshots, d.nmonitor, d.monitor_timestep = 10, 1000, 31.41526e1
+    d.write_massflow = 1
+    return d
+
+
+# 1e-8 solMass/yr in code units (code time = yr / 2 pi for l0 = 1 au, m0 = 1 solMass)
+MDOT_STEADY_CODE = 1.0e-8 * (_T0 / 3.15576e7)

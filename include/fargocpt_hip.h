@@ -90,9 +90,11 @@ enum {
      * FCPT_EINVAL otherwise */
     FCPT_F_VISC_CFAC_PHI = 16,
     FCPT_F_VISC_CFAC_R = 17,
-    /* MASSFLOW (src/data.h), (Nr+1) x Nphi: the radial mass flux of the last Transport() through every
-     * interface, VanLeerRadial's "if (Q == &data[t_data::SIGMA])" branch (src/TransportEuler.cpp:579-615):
-     * mass per step, signed like v_r.  Materialised by the next fcpt_download(FCPT_F_MASSFLOW); not uploadable. */
+    /* MASSFLOW (src/data.h:76), (Nr+1) x Nphi, only with fcpt_desc.write_massflow: the mass every Transport()
+     * carried through the inner interface of each cell, accumulated step by step as VanLeerRadial does for the
+     * density (src/TransportEuler.cpp:609-616: "+= varq_inf").  The caller divides by the elapsed
+     * Nmonitor * MonitorTimestep (quantities::calculate_massflow, src/quantities.cpp:770-781), sums over azimuth
+     * for MassFlow1D.dat and clears the grid by uploading zeros (clear_after_write, src/data.cpp:277). */
     FCPT_F_MASSFLOW = 18,
     FCPT_F_COUNT = 19
 };
@@ -220,6 +222,9 @@ typedef struct fcpt_desc {
     double profile_cutoff_width_inner;  /* ProfileCutoffWidthInner */
     double profile_cutoff_point_outer;  /* ProfileCutoffPointOuter */
     double profile_cutoff_width_outer;  /* ProfileCutoffWidthOuter */
+    /* monitoring that rides on the path */
+    int32_t write_massflow; /* WriteMassFlow: accumulate the radial mass flux of every Transport() in FCPT_F_MASSFLOW */
+    int32_t _pad5;
 } fcpt_desc;
 
 /* Row ranges of a slab, exactly the integers of src/split.cpp:56-78. */

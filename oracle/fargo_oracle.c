@@ -20,8 +20,8 @@
  *
  * Out of scope (not restated): N-body integration, self-gravity, FLD, dust,
  * S-curve cooling and the Bell opacity, variable-gamma EOS,
- * BodyForceFromPotential=no, composite BCs (custom / centerofmass), mass-flow
- * bookkeeping (MassDelta).
+ * BodyForceFromPotential=no, composite BCs (custom / centerofmass), the MassDelta
+ * boundary bookkeeping (the MASSFLOW grid of WriteMassFlow is restated).
  */
 #include "fargo_oracle.h"
 
@@ -54,6 +54,7 @@ struct orc_ctx {
     double *qr, *qphi, *divv, *trr, *tpp, *trp /* vector */, *qplus, *qminus, *density_int;
     double *nusig, *nusig_rp /* vector */, *cfac_phi, *cfac_r; /* StabilizeViscosity (viscosity.cpp:256-348) */
     double *tau_eff; /* kappa_eff (compute.cpp:41-87); 0 without surface cooling */
+    double *massflow; /* MASSFLOW (data.h:76), vector grid; NULL without WriteMassFlow */
     double btemp[FCPT_MAX_BODIES], bradius[FCPT_MAX_BODIES], bramp[FCPT_MAX_BODIES]; /* irradiating bodies */
     int heating_star; /* parameters::heating_star_enabled */
     /* transport scratch (TransportEuler.cpp:32-50) */
@@ -671,6 +672,7 @@ int orc_create(const fcpt_desc *d, const double *radii, orc_ctx **out)
     c->cfac_phi = dalloc(ns);
     c->cfac_r = dalloc(ns);
     c->tau_eff = dalloc(ns);
+    c->massflow = c->d.write_massflow ? dalloc(nv) : NULL;
     c->rmp = dalloc(ns);
     c->rmm = dalloc(ns);
     c->lp = dalloc(ns);
@@ -710,7 +712,7 @@ int orc_destroy(orc_ctx *c)
                      &c->trp,        &c->qplus,     &c->qminus,      &c->density_int, &c->tau_eff, &c->nusig, &c->nusig_rp, &c->cfac_phi, &c->cfac_r,
                      &c->rmp,        &c->rmm,       &c->lp,          &c->lm,          &c->vres,
                      &c->vmean,      &c->work,      &c->qrstar,      &c->densstar,    &c->tempshift,
-                     &c->dq,         &c->cfl_vmean, &c->cfl_vres};
+                     &c->dq,         &c->cfl_vmean, &c->cfl_vres,    &c->massflow};
     for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]); ++i)
         free(*ps[i]);
     free(c->nshift);
@@ -764,6 +766,7 @@ static double *field_ptr(orc_ctx *c, int32_t f, size_t *n)
     case FCPT_F_QMINUS: return c->qminus;
     case FCPT_F_VISC_CFAC_PHI: return c->d.stabilize_viscosity ? c->cfac_phi : NULL;
     case FCPT_F_VISC_CFAC_R: return c->d.stabilize_viscosity ? c->cfac_r : NULL;
+    case FCPT_F_MASSFLOW: *n = nv; return c->massflow;
     default: return NULL;
     }
 }
@@ -2014,10 +2017,11 @@ static void divise(const orc_ctx *c, const double *num, const double *den, doubl
     for (size_t i = 0; i < n; ++i)
         res[i] = num[i] / den[i];
 }
-/* TransportEuler.cpp:545-620 VanLeerRadial (mass-flow bookkeeping omitted) */
+/* TransportEuler.cpp:545-620 VanLeerRadial (of the mass-flow bookkeeping: the MASSFLOW grid, :609-616) */
 static void VanLeerRadial(orc_ctx *c, const double *VRadial, double *Qbase, double dt)
 {
     const int Nr = c->nr, Nphi = c->nphi;
+    const int is_density = Qbase == c->sigma;
     divise(c, Qbase, c->density_int, c->work);
     compute_star_radial(c, c->work, VRadial, c->qrstar, dt);
 #pragma omp parallel for if (c->big)
@@ -2030,6 +2034,11 @@ static void VanLeerRadial(orc_ctx *c, const double *VRadial, double *Qbase, doub
             const double varq_sup =
                 dt * c->dphi * c->Rsup[nr] * c->qrstar[lip] * c->densstar[lip] * VRadial[lip];
             Qbase[cell] += (varq_inf - varq_sup) * c->InvSurf[nr];
+            if (is_density && c->massflow) { /* parameters::write_massflow */
+                c->massflow[cell] += varq_inf;
+                if (c->s.is_last && nr == Nr - 1) /* Qbase->get_max_radial() */
+                    c->massflow[cell] += varq_sup;
+            }
         }
 }
 /* TransportEuler.cpp:138-167 OneWindRad */

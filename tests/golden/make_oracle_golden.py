@@ -2,7 +2,7 @@
 """Regenerates tests/golden/oracle_reference_runs.json from the CPU oracle.
 
 Runs the reference's known-answer setups (test/shockTube/setups/shocktube_{SN,TW}.yml,
-test/spreading_ring/setup.yml) to their snapshot time and records step counts, deviation
+test/spreading_ring/setup.yml, test/steady_state_accretion/setup.yml) to their snapshot time and records step counts, deviation
 metrics and field checksums.  Takes ~15 s."""
 import ctypes
 import json
@@ -17,7 +17,8 @@ os.environ.setdefault("OMP_NUM_THREADS", "4")
 
 import fargocpt_amd  # noqa: E402
 from fargocpt_amd import binding as B, driver, setups  # noqa: E402
-from tests.known_answers import shocktube_deviations, spreading_ring_deviation  # noqa: E402
+from tests.known_answers import (run_steady_accretion, shocktube_deviations, spreading_ring_deviation,  # noqa: E402
+                                 steady_accretion_deviation)
 
 
 def main():
@@ -44,6 +45,11 @@ def main():
     out["spreading_ring_256x2"] = {
         "steps": n, "time": ctx.clock.time, "mean_rel_deviation": spreading_ring_deviation(lib, d, ctx),
         "sum_sigma": float(st["sigma"].sum()), "max_vrad": float(np.abs(st["vrad"]).max())}
+    d = setups.steady_state_accretion(lib)
+    mf, steps = run_steady_accretion(orc, lib, d)
+    out["steady_state_accretion_198x1"] = {
+        "steps": steps, "max_rel_deviation": steady_accretion_deviation(lib, d, mf),
+        "massflow_code_units_at_interface_100": float(mf[100])}
     path = os.path.join(ROOT, "tests", "golden", "oracle_reference_runs.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

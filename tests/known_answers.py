@@ -45,3 +45,38 @@ def spreading_ring_deviation(lib, d, ctx):
     tau = 12 * nu * t + tau0
     theo = 1.0 / np.pi / tau / rc ** 0.25 * iv(0.25, 2.0 * rc / tau) * np.exp(-(1 + rc ** 2) / tau)
     return float(np.mean(np.abs(sigma / theo - 1)))
+
+
+STEADY_ACCRETION_THRESHOLD = 2.2e-4   # test/steady_state_accretion/testconfig.yml:2
+
+
+def steady_accretion_deviation(lib, d, massflow_1d):
+    """test/steady_state_accretion/check_results.py:104-118: max |MassFlow / 1e-8 solMass/yr| - 1 over the interfaces
+    between 20 and 60 au.  `massflow_1d`: the Nr + 1 values of MassFlow1D.dat of the last snapshot (code units:
+    azimuthal sum of MASSFLOW divided by Nmonitor * MonitorTimestep)."""
+    from fargocpt_amd import setups
+    radii = lib.radii(d)
+    ri, rs = radii[:d.nr_global], radii[1:d.nr_global + 1]
+    x = 2.0 / 3.0 * (rs ** 3 - ri ** 3) / (rs ** 2 - ri ** 2)   # Rmed: the radii of Sigma1D.dat
+    diffval = np.abs(np.asarray(massflow_1d)[1:-1]) / setups.MDOT_STEADY_CODE - 1
+    inds = np.logical_and(x[1:] > 20.0, x[:-1] < 60.0)
+    return float(np.max(np.abs(diffval[inds])))
+
+
+def run_steady_accretion(lib_run, lib_host, d):
+    """The reference's run of that setup through the ABI: Nsnapshots x Nmonitor monitor steps with snapping; at
+    every snapshot MASSFLOW is divided by Nmonitor * MonitorTimestep, summed over azimuth (MassFlow1D.dat) and
+    cleared (quantities.cpp:770-781, data.cpp:276-278).  Returns (MassFlow1D of the last snapshot, hydro steps)."""
+    from fargocpt_amd import driver
+    ctx = driver.make_context(lib_run, d)
+    S = driver.SlabSet([ctx])
+    S.prepare()
+    steps, mf = 0, None
+    for snap in range(1, d.nsnapshots + 1):
+        t_end = snap * d.nmonitor * d.monitor_timestep
+        while ctx.clock.time < t_end * (1.0 - 1e-14):
+            steps += ctx.run_steps(1, snap=True)
+        mf = ctx.download(B.F_MASSFLOW).sum(axis=1) / (d.nmonitor * d.monitor_timestep)
+        ctx.upload(B.F_MASSFLOW, np.zeros((d.nr_global + 1, d.nphi)))
+    ctx.close()
+    return mf, steps

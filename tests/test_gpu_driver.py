@@ -11,7 +11,7 @@ import pytest
 from scipy import integrate, interpolate
 from scipy.special import iv
 
-from tests.known_answers import GOLDEN, SHOCKTUBE_THRESHOLDS, SPREADING_RING_THRESHOLD
+from tests.known_answers import GOLDEN, SHOCKTUBE_THRESHOLDS, SPREADING_RING_THRESHOLD, STEADY_ACCRETION_THRESHOLD
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,6 +74,29 @@ def test_shocktube_setup_files(tmp_path, setup, steps):
         spl = interpolate.InterpolatedUnivariateSpline(an[:, 1], y)
         diff = integrate.simpson(np.abs(data[inds] - spl(r1[inds])), x=r1[inds])
         assert diff < thr, (quant, diff, thr)
+
+
+def test_steady_state_accretion_setup_file(tmp_path, product):
+    """test/steady_state_accretion/setup.yml (198 x 1 cells, WriteMassFlow) through the driver: MassFlow1D.dat of the
+    last snapshot against the reference's criterion (check_results.py:104-118, threshold 2.2e-4) and against the
+    oracle's run of the same setup (tests/golden/oracle_reference_runs.json: same step count, same deviation)."""
+    import json
+    from fargocpt_amd import setups
+    from tests.known_answers import steady_accretion_deviation
+    out = _run(tmp_path, "steady_state_accretion.yml", "acc")
+    gold = json.load(open(os.path.join(GOLDEN, "oracle_reference_runs.json")))["steady_state_accretion_198x1"]
+    snaps = open(out + "snapshots/list.txt").read().split()
+    assert snaps == [str(n) for n in range(11)]
+    misc = _misc(out + "snapshots/10/misc.bin")
+    assert misc["n_iter"] == gold["steps"]
+    pairs = np.fromfile(out + "snapshots/10/MassFlow1D.dat").reshape(-1, 2)
+    assert pairs.shape[0] == 199
+    assert np.allclose(pairs[:, 0], np.loadtxt(out + "used_rad.dat"), rtol=1e-15)
+    d = setups.steady_state_accretion(product)
+    dev = steady_accretion_deviation(product, d, pairs[:, 1])
+    assert dev < STEADY_ACCRETION_THRESHOLD
+    assert dev == pytest.approx(gold["max_rel_deviation"], rel=1e-6)
+    assert pairs[100, 1] == pytest.approx(gold["massflow_code_units_at_interface_100"], rel=1e-9)
 
 
 def test_spreading_ring_setup_file(tmp_path):

@@ -608,3 +608,37 @@ def test_recalculate_derived_and_device_pointers(product, oracle, adiabatic):
         ctx.close()
     for f, a in derived["hip"].items():
         assert rel_err(a, derived["oracle"][f]) <= 1e-13, f
+
+
+@pytest.mark.parametrize("nr,nphi,adiabatic,leapfrog", [(64, 320, False, False), (48, 96, True, False), (40, 3, False, True),
+                                                        (198, 1, False, False)])
+def test_massflow_grid(product, oracle, nr, nphi, adiabatic, leapfrog):
+    """WriteMassFlow: the MASSFLOW grid (VanLeerRadial's density flux accumulated step by step,
+    TransportEuler.cpp:609-616) after 12 steps, on the marching-kernel path, the narrow-ring path and a
+    one-cell ring."""
+    from fargocpt_amd import driver
+    d = setups.planet_disk(product, nr, nphi, adiabatic=adiabatic) if nphi > 1 else setups.steady_state_accretion(product, nr, nphi)
+    d.write_massflow = 1
+    if leapfrog:
+        d.integrator = B.INTEGRATOR_LEAPFROG
+    got = []
+    for L in (product, oracle):
+        ctx = driver.make_context(L, d, bodies=setups.jupiter_bodies(d) if nphi > 1 else None)
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        S.run(12)
+        got.append((ctx.download(B.F_MASSFLOW), ctx.state()))
+        ctx.upload(B.F_MASSFLOW, np.zeros((nr + 1, nphi)))   # clear_after_write
+        assert not ctx.download(B.F_MASSFLOW).any()
+        ctx.close()
+    (ma, sa), (mb, sb) = got
+    assert np.abs(mb).max() > 0 and not mb[0].any() and not mb[nr].any()
+    assert rel_err(ma, mb) <= TOL
+    for k in sa:
+        assert rel_err(sa[k], sb[k]) <= TOL, k
+    # without the switch the grid does not exist
+    d.write_massflow = 0
+    ctx = driver.make_context(product, d)
+    with pytest.raises(B.FcptError, match="FCPT_EINVAL"):
+        ctx.download(B.F_MASSFLOW)
+    ctx.close()

@@ -14,8 +14,9 @@ import numpy as np
 import pytest
 
 from fargocpt_amd import binding as B, driver, setups
-from tests.known_answers import (GOLDEN, SHOCKTUBE_THRESHOLDS, SPREADING_RING_THRESHOLD,
-                                 shocktube_deviations, spreading_ring_deviation)
+from tests.known_answers import (GOLDEN, SHOCKTUBE_THRESHOLDS, SPREADING_RING_THRESHOLD, STEADY_ACCRETION_THRESHOLD,
+                                 run_steady_accretion, shocktube_deviations, spreading_ring_deviation,
+                                 steady_accretion_deviation)
 
 GOLD = json.load(open(os.path.join(GOLDEN, "oracle_reference_runs.json")))
 
@@ -54,6 +55,24 @@ def test_spreading_ring_analytic(product, oracle):
     dev = spreading_ring_deviation(product, d, ctx)
     assert dev < SPREADING_RING_THRESHOLD
     assert dev == pytest.approx(GOLD["spreading_ring_256x2"]["mean_rel_deviation"], rel=1e-9)
+
+
+def test_steady_state_accretion_reference_criterion(product, oracle):
+    """test/steady_state_accretion (setup.yml + check_results.py:104-118, threshold of testconfig.yml): alpha = 0.1,
+    h = 0.005, Sigma ~ r^-1/2 on 198 x 1 cells with outflow boundaries and damping of Sigma and v_r to the initial
+    profile: the mass flux through every interface between 20 and 60 au, averaged over the last of ten snapshot
+    intervals (3.1e5 time units each), is 3 pi Sigma nu = 1e-8 solMass/yr to 2.2e-4.  Pins the alpha-viscosity
+    stress + velocity update in a locally isothermal disk, the radial transport's density flux (the MASSFLOW
+    bookkeeping of VanLeerRadial, TransportEuler.cpp:609-616), the outflow boundary and the reference damping --
+    none of which the Nphi = 2 fixtures above exercise with a net flow."""
+    d = setups.steady_state_accretion(product)
+    mf, steps = run_steady_accretion(oracle, product, d)
+    dev = steady_accretion_deviation(product, d, mf)
+    assert dev < STEADY_ACCRETION_THRESHOLD, dev
+    assert (mf[60:120] < 0).all()   # inward (interfaces 60..119 lie between 20 and 40 au)
+    g = GOLD["steady_state_accretion_198x1"]
+    assert steps == g["steps"]
+    assert dev == pytest.approx(g["max_rel_deviation"], rel=1e-6)
 
 
 def test_mass_conservation_closed_box(product, oracle):
