@@ -136,7 +136,7 @@ def main():
     os.dup2(2, 1)
     os.environ.setdefault("RCCL_LOG_LEVEL", "0")
     os.environ.setdefault("OMP_NUM_THREADS", str(affinity_threads()))
-    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("GOMP_SPINCOUNT", "100000")  # idle OpenMP threads spin ~0.1 ms, then sleep
 
     import numpy as np
     import torch  # first: the HIP runtime torch bundles must be the one the library binds to

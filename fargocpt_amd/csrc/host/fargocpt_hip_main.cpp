@@ -114,11 +114,13 @@ struct Config {
     }
 };
 
-// code units of the default unit system (src/units.cpp:158-185)
+// code units (set_baseunits, src/units.cpp:131-185): l0 and m0 from the setup (default 1 au, 1 solMass), time and
+// temperature units derived with G = 1 and R_gas = 1
 const double G_CGS = 6.67430e-8, KB = 1.380649e-16, MU = 1.66053906660e-24;
-const double L0 = 1.495978707e13, M0 = 1.988409870698051e33;
-const double TEMP0 = G_CGS * MU / KB * M0 / L0;
-const double TIME0 = std::sqrt(L0 * L0 * L0 / (G_CGS * M0));
+const double AU_CM = 1.495978707e13, SOLMASS_G = 1.988409870698051e33;
+double L0 = AU_CM, M0 = SOLMASS_G;
+double TEMP0 = G_CGS * MU / KB * M0 / L0;
+double TIME0 = std::sqrt(L0 * L0 * L0 / (G_CGS * M0));
 
 // "<number> [unit]" -> code units for the quantity kind
 enum Kind { K_NONE, K_LEN, K_MASS, K_SIGMA, K_TEMP, K_VISC };
@@ -134,18 +136,18 @@ double number(const std::string &s, Kind kind)
         return v;
     if (kind == K_LEN) {
         if (u == "au")
-            return v;
+            return v * AU_CM / L0;
         if (u == "cm")
             return v / L0;
         if (u == "solradius")
             return v * 6.957e10 / L0;
     } else if (kind == K_MASS) {
         if (u == "solmass")
-            return v;
+            return v * SOLMASS_G / M0;
         if (u == "jupitermass")
-            return v * 9.547919e-4;
+            return v * 9.547919e-4 * SOLMASS_G / M0;
         if (u == "earthmass")
-            return v * 3.0034893e-6;
+            return v * 3.0034893e-6 * SOLMASS_G / M0;
     } else if (kind == K_SIGMA) {
         if (u == "g/cm2")
             return v / (M0 / (L0 * L0));
@@ -196,6 +198,35 @@ int damp_of(const std::string &s) // damping.cpp:152-178
 void config_to_desc(const Config &c, fcpt_desc &d)
 {
     fcpt_desc_default(&d);
+    { // base units: "l0: 30 au" / "m0: 1 solMass", or plain numbers in au / solMass (units.cpp:131-160)
+        auto base = [&](const char *key, double unit_cgs, const char *unit_name) {
+            std::istringstream is(c.str(key, "1.0"));
+            double v = 1.0;
+            std::string u;
+            is >> v >> u;
+            if (!u.empty() && lower(u) != unit_name) {
+                fprintf(stderr, "fargocpt_hip: %s: unit '%s' not understood (%s)\n", key, u.c_str(), unit_name);
+                exit(2);
+            }
+            return v * unit_cgs;
+        };
+        L0 = base("l0", AU_CM, "au");
+        M0 = base("m0", SOLMASS_G, "solmass");
+        TEMP0 = G_CGS * MU / KB * M0 / L0;
+        TIME0 = std::sqrt(L0 * L0 * L0 / (G_CGS * M0));
+        if (L0 != AU_CM || M0 != SOLMASS_G) {
+            // the code-unit values of sigma_SB, c and the cgs factors of the opacity laws (constants.cpp:236-262), with
+            // the expressions fcpt_desc_default uses for the default units
+            const double h_cgs = 6.62607015e-27, c_cgs = 2.99792458e10;
+            const double E0 = M0 * L0 * L0 / (TIME0 * TIME0);
+            const double sigma_cgs = 2. * std::pow(M_PI, 5) * std::pow(KB, 4) / (15. * std::pow(h_cgs, 3) * std::pow(c_cgs, 2));
+            d.temperature_cgs = TEMP0;
+            d.density_cgs = M0 / (L0 * L0 * L0);
+            d.opacity_cgs = L0 * L0 / M0;
+            d.sigma_sb = sigma_cgs / (E0 / (L0 * L0 * TIME0 * TEMP0 * TEMP0 * TEMP0 * TEMP0));
+            d.c_light = c_cgs / (L0 / TIME0);
+        }
+    }
     d.nr_global = (int)num(c, "Nrad", 64);
     d.nphi = (int)num(c, "Naz", 64);
     d.rmin = num(c, "Rmin", d.rmin, K_LEN);
@@ -219,6 +250,21 @@ void config_to_desc(const Config &c, fcpt_desc &d)
             d.aspect_ratio = std::sqrt(t0 * d.Rgas / d.mu);
     }
     d.flaring_index = num(c, "FlaringIndex", 0.0);
+    { // cps: cells per scale height overwrite Nrad and Naz (Interpret.cpp:206-228)
+        const double cps = num(c, "cps", -1.0), H = d.aspect_ratio;
+        if (cps > 0) {
+            if (d.radial_spacing == FCPT_SPACING_ARITHMETIC) {
+                d.nr_global = (int)std::round(cps * (d.rmax - d.rmin) / H);
+                d.nphi = (int)std::round(2 * M_PI / (d.rmax - d.rmin) * d.nr_global);
+            } else if (d.radial_spacing == FCPT_SPACING_LOGARITHMIC) {
+                d.nr_global = (int)std::round(std::log(d.rmax / d.rmin) / std::log(1 + H / cps));
+                d.nphi = (int)std::round(2 * M_PI / (std::pow(d.rmax / d.rmin, 1.0 / (double)d.nr_global) - 1));
+            } else {
+                fprintf(stderr, "fargocpt_hip: Setting resolution is not supported for the selected radial grid spacing.\n");
+                exit(2);
+            }
+        }
+    }
     d.minimum_temperature = num(c, "MinimumTemperature", 3.0 / TEMP0, K_TEMP);
     d.maximum_temperature = num(c, "MaximumTemperature", 1.0e300 / TEMP0, K_TEMP);
     d.sigma0 = num(c, "Sigma0", 173.0 / (M0 / (L0 * L0)), K_SIGMA);
@@ -339,6 +385,7 @@ void config_to_desc(const Config &c, fcpt_desc &d)
 
 struct Body {
     double a, m, phase, rsm_factor;
+    double rampup; // "ramp-up time" in orbital periods (planet.cpp:166-179)
 };
 
 void mkdirs(const std::string &p)
@@ -483,10 +530,11 @@ int main(int argc, char **argv)
         o.m = b.count("mass") ? number(b.at("mass"), K_MASS) : 0.0;
         o.phase = 0.0;
         o.rsm_factor = b.count("cubic smoothing factor") ? number(b.at("cubic smoothing factor"), K_NONE) : 0.0;
+        o.rampup = b.count("ramp-up time") ? number(b.at("ramp-up time"), K_NONE) : 0.0;
         bodies.push_back(o);
     }
     if (bodies.empty())
-        bodies.push_back({0.0, d.hydro_center_mass, 0.0, 0.0});
+        bodies.push_back({0.0, d.hydro_center_mass, 0.0, 0.0, 0.0});
 
     std::vector<double> radii(d.nr_global + FCPT_GEOM_PAD + 1);
     CHECK(fcpt_radii(&d, radii.data()));
@@ -525,9 +573,17 @@ int main(int argc, char **argv)
     CHECK(fcpt_upload(ctx, FCPT_F_VAZI, vazi.data()));
     CHECK(fcpt_upload(ctx, FCPT_F_ENERGY, energy.data()));
 
-    auto set_bodies = [&](double t) {
+    // Bodies at time t for the potential of a step of length dt (CalculateNbodyPotential, Pframeforce.cpp:21-94):
+    // positions on the circular orbits, masses ramped up (get_rampup_mass, planet.cpp:166-179), and the indirect term
+    // of the star-centred frame without the disk (refframe::IndirectTermPlanets): minus the acceleration of the star,
+    // which the reference takes as the velocity change of the hydro centre over the step divided by dt
+    // (ComputeIndirectTermNbody, frame_of_reference.cpp:138-160) -- for circular orbits the time average of
+    // G m r_p / a^3 over [t, t + dt], in closed form.
+    const bool indirect = lower(cfg.str("HydroFrameCenter", "primary")) == "primary";
+    auto set_bodies = [&](double t, double dt) {
         double x[FCPT_MAX_BODIES], y[FCPT_MAX_BODIES], m[FCPT_MAX_BODIES], rsm[FCPT_MAX_BODIES];
         const int n = (int)std::min<size_t>(bodies.size(), FCPT_MAX_BODIES);
+        double itx = 0.0, ity = 0.0;
         for (int k = 0; k < n; ++k) {
             const Body &b = bodies[k];
             const double om = b.a > 0 ? std::sqrt(d.G * (d.hydro_center_mass + b.m) / (b.a * b.a * b.a)) : 0.0;
@@ -535,12 +591,24 @@ int main(int argc, char **argv)
             x[k] = b.a * std::cos(ang);
             y[k] = b.a * std::sin(ang);
             m[k] = b.m;
+            if (b.rampup > 0 && om > 0) {
+                const double period = 2 * M_PI / om;
+                if (t < b.rampup * period) {
+                    const double cs = std::cos(t * M_PI_2 / (b.rampup * period));
+                    m[k] = b.m * (1.0 - cs * cs);
+                }
+            }
             // dimensionless Roche radius ~ (q/3)^(1/3) (Theo.cpp:251-277 converges to it for small q)
             rsm[k] = b.a * std::cbrt(b.m / (3.0 * d.hydro_center_mass)) * b.rsm_factor;
+            if (indirect && k > 0 && b.a > 0 && dt > 0) {
+                const double g = d.G * b.m / (b.a * b.a), w = om * dt;
+                itx -= g * (std::sin(ang + w) - std::sin(ang)) / w;
+                ity -= g * (std::cos(ang) - std::cos(ang + w)) / w;
+            }
         }
-        CHECK(fcpt_set_bodies(ctx, n, x, y, m, rsm, 0.0, 0.0));
+        CHECK(fcpt_set_bodies(ctx, n, x, y, m, rsm, itx, ity));
     };
-    set_bodies(0.0);
+    set_bodies(0.0, 0.0);
     { // irradiating bodies: 'temperature', 'radius', 'irradiation ramp-up time' (planetary_system.cpp:160-250)
         double temp[FCPT_MAX_BODIES] = {0}, rad[FCPT_MAX_BODIES] = {0}, ramp[FCPT_MAX_BODIES] = {0};
         bool any = false;
@@ -758,7 +826,7 @@ int main(int argc, char **argv)
         time = misc.time;
         n_monitor = misc.nTimeStep;
         n_iter = n_iter_last = misc.N_iter;
-        set_bodies(time);
+        set_bodies(time, 0.0);
         CHECK(fcpt_recalculate_derived(ctx));
         if (!quiet)
             printf("Restarting from %s at time %f (snapshot %u, monitor step %u).\n", restart_dir.c_str(), time,
@@ -790,7 +858,7 @@ int main(int argc, char **argv)
         CHECK(fcpt_snap_to_monitor(ctx, cfl_dt, &step_dt));
         const double time_next_monitor = (n_monitor + 1) * d.monitor_timestep;
         if (moving)
-            set_bodies(time);
+            set_bodies(time, step_dt);
         CHECK(fcpt_step(ctx, step_dt));
         CHECK(fcpt_post(ctx, step_dt));
         time += step_dt;

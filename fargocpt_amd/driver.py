@@ -116,3 +116,70 @@ class SlabSet:
                 parts.append(a[lo:hi])
             out[name] = np.concatenate(parts, axis=0)
         return out
+
+
+class CircularOrbits:
+    """The N-body stand-in of the host driver (csrc/host/fargocpt_hip_main.cpp, set_bodies): the star at the origin,
+    every planet on its initial circular orbit seen in the frame rotating with OmegaFrame, its mass ramped up as
+    t_planet::get_rampup_mass does (nbody/planet.cpp:166-179), and the indirect term of the star-centred frame
+    without the disk (refframe::IndirectTermPlanets, frame_of_reference.cpp:138-160: minus the star's velocity
+    change over the step divided by dt; for circular orbits the time average of G m r_p / a^3 over [t, t + dt])."""
+
+    def __init__(self, d: B.Desc, bodies):
+        self.d = d
+        self.bodies = list(bodies)   # (semi-major axis, mass, ramp-up time in orbital periods)
+
+    def at(self, t: float, dt: float):
+        import math
+        d = self.d
+        x, y, m = [], [], []
+        itx = ity = 0.0
+        for k, (a, mass, ramp) in enumerate(self.bodies):
+            om = math.sqrt(d.G * (d.hydro_center_mass + mass) / (a * a * a)) if a > 0 else 0.0
+            ang = (om - d.omega_frame) * t
+            x.append(a * math.cos(ang))
+            y.append(a * math.sin(ang))
+            mk = mass
+            if ramp > 0 and om > 0:
+                period = 2 * math.pi / om
+                if t < ramp * period:
+                    cs = math.cos(t * (math.pi / 2) / (ramp * period))
+                    mk = mass * (1.0 - cs * cs)
+            m.append(mk)
+            if k > 0 and a > 0 and dt > 0:
+                g, w = d.G * mass / (a * a), om * dt
+                itx -= g * (math.sin(ang + w) - math.sin(ang)) / w
+                ity -= g * (math.cos(ang) - math.cos(ang + w)) / w
+        return x, y, m, None, (itx, ity)
+
+
+def run_to_snapshots(ctx: B.Context, d: B.Desc, orbits: "CircularOrbits | None" = None, on_snapshot=None,
+                     max_snapshots=None) -> int:
+    """sim::run (simulation.cpp:505-558) for one slab with moving bodies: CFL, CalculateTimeStep, monitor-time
+    snapping, bodies at the step's start, step, post; `on_snapshot(n)` at every Nmonitor-th monitor time.
+    Returns the number of hydro steps."""
+    s = SlabSet([ctx])
+    s.prepare()
+    steps, n_monitor = 0, 0
+    nsnap = d.nsnapshots if max_snapshots is None else min(d.nsnapshots, max_snapshots)
+    t_final = nsnap * d.nmonitor * d.monitor_timestep
+    time = 0.0
+    while time < t_final:
+        cfl_dt = ctx.calculate_timestep(ctx.cfl())
+        step_dt = ctx.snap_to_monitor(cfl_dt)
+        t_next = (n_monitor + 1) * d.monitor_timestep
+        if orbits is not None and len(orbits.bodies) > 1:
+            ctx.set_bodies(*orbits.at(time, step_dt))
+        ctx.step(step_dt)
+        ctx.post(step_dt)
+        time += step_dt
+        steps += 1
+        if abs(t_next - time) < 1e-6 * cfl_dt:
+            n_monitor += 1
+            c = ctx.clock
+            c.n_monitor = n_monitor
+            c.n_snapshot = n_monitor // d.nmonitor
+            ctx.clock = c
+            if n_monitor % d.nmonitor == 0 and on_snapshot is not None:
+                on_snapshot(n_monitor // d.nmonitor)
+    return steps

@@ -236,3 +236,44 @@ def steady_state_accretion(lib: B.Library, nr=198, nphi=1) -> B.Desc:
 
 # 1e-8 solMass/yr in code units (code time = yr / 2 pi for l0 = 1 au, m0 = 1 solMass)
 MDOT_STEADY_CODE = 1.0e-8 * (_T0 / 3.15576e7)
+
+
+def cold_disk(lib: B.Library, planet=False):
+    """test/cold_disk/setup.yml and test/cold_disk_planet/setup.yml: an inviscid power-law disk with the ideal EOS
+    and neither heating nor cooling must keep its temperature profile (to 10 % over 20 orbits; with a 2e-5 planet,
+    TW artificial viscosity and 100 orbits in the second setup).  Base length 30 au; the grid comes from
+    `cps: 3` cells per scale height (Interpret.cpp:206-228).  Returns (desc, bodies) with bodies = [(a, mass,
+    ramp-up time in orbits)] for driver.CircularOrbits."""
+    import math
+    d = lib.desc_default()
+    temp0_k = TEMP0_K / 30.0   # l0 = 30 au
+    d.rmin, d.rmax, d.radial_spacing = 0.4, 2.0, B.SPACING_LOGARITHMIC
+    d.aspect_ratio, d.flaring_index = 0.05, 0.2857142857142857
+    cps = 3.0
+    d.nr_global = int(round(math.log(d.rmax / d.rmin) / math.log(1 + d.aspect_ratio / cps)))
+    d.nphi = int(round(2 * math.pi / ((d.rmax / d.rmin) ** (1.0 / d.nr_global) - 1)))
+    d.ic = B.IC_PROFILE
+    d.sigma0, d.sigma_slope, d.sigma_floor = 0.005743125733951172, 1.0, 1e-7
+    d.viscous_alpha, d.constant_viscosity = 0.0, 0.0
+    if planet:
+        d.artificial_viscosity, d.artificial_viscosity_dissipation, d.artificial_viscosity_factor = B.ARTVISC_TW, 1, 3.0
+    else:
+        d.artificial_viscosity, d.artificial_viscosity_dissipation, d.artificial_viscosity_factor = B.ARTVISC_NONE, 0, 1.41
+    d.eos, d.adiabatic_index, d.mu = B.EOS_IDEAL, 1.4, 2.35
+    d.heating_viscous = 0
+    d.minimum_temperature, d.maximum_temperature = 3.0 / temp0_k, 1e100 / temp0_k
+    d.cfl, d.cfl_max_var, d.first_dt, d.heating_cooling_cfl_limit = 0.5, 1.1, 1.0e-1, 1.0
+    d.thickness_smoothing = 0.6
+    d.fast_transport = 1
+    d.omega_frame = 0.0
+    _composite(d, 0, "reflecting")
+    _composite(d, 1, "reflecting")
+    d.damping = 1
+    d.damping_inner_limit, d.damping_outer_limit = 1.311, 0.763
+    d.damping_time_factor, d.damping_time_radius_outer = 0.05, d.rmax
+    for arr in (d.damp_vrad, d.damp_vaz, d.damp_sigma, d.damp_energy):
+        arr[0] = arr[1] = B.DAMP_REFERENCE
+    d.monitor_timestep = 0.6283185307179586
+    d.nmonitor, d.nsnapshots = (100, 10) if planet else (10, 20)
+    bodies = [(0.0, d.hydro_center_mass, 0.0)] + ([(1.0, 2e-5, 10.0)] if planet else [])
+    return d, bodies

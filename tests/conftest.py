@@ -8,7 +8,7 @@ import pytest
 # The oracle is OpenMP code: pin its team size before libgomp starts, otherwise a box
 # that reports more processors than its CPU quota oversubscribes and crawls.
 os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, len(os.sched_getaffinity(0))))))
-os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "100000")  # idle OpenMP threads spin ~0.1 ms, then sleep
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

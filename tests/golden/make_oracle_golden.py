@@ -2,8 +2,8 @@
 """Regenerates tests/golden/oracle_reference_runs.json from the CPU oracle.
 
 Runs the reference's known-answer setups (test/shockTube/setups/shocktube_{SN,TW}.yml,
-test/spreading_ring/setup.yml, test/steady_state_accretion/setup.yml) to their snapshot time and records step counts, deviation
-metrics and field checksums.  Takes ~15 s."""
+test/spreading_ring/setup.yml, test/steady_state_accretion/setup.yml, test/cold_disk(_planet)/setup.yml) to their snapshot time and records step counts, deviation
+metrics and field checksums.  Takes ~2 min."""
 import ctypes
 import json
 import os
@@ -17,7 +17,7 @@ os.environ.setdefault("OMP_NUM_THREADS", "4")
 
 import fargocpt_amd  # noqa: E402
 from fargocpt_amd import binding as B, driver, setups  # noqa: E402
-from tests.known_answers import (run_steady_accretion, shocktube_deviations, spreading_ring_deviation,  # noqa: E402
+from tests.known_answers import (run_cold_disk, run_steady_accretion, shocktube_deviations, spreading_ring_deviation,  # noqa: E402
                                  steady_accretion_deviation)
 
 
@@ -50,6 +50,9 @@ def main():
     out["steady_state_accretion_198x1"] = {
         "steps": steps, "max_rel_deviation": steady_accretion_deviation(lib, d, mf),
         "massflow_code_units_at_interface_100": float(mf[100])}
+    out["cold_disk"] = run_cold_disk(orc, lib, planet=False)          # 20 orbits, ~10 s
+    out["cold_disk_planet"] = run_cold_disk(orc, lib, planet=True)    # 100 orbits, ~1 min
+    out["cold_disk_planet_first_snapshot"] = run_cold_disk(orc, lib, planet=True, max_snapshots=1)
     path = os.path.join(ROOT, "tests", "golden", "oracle_reference_runs.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

@@ -80,3 +80,26 @@ def run_steady_accretion(lib_run, lib_host, d):
         ctx.upload(B.F_MASSFLOW, np.zeros((d.nr_global + 1, d.nphi)))
     ctx.close()
     return mf, steps
+
+
+COLD_DISK_THRESHOLD = 0.1   # test/cold_disk/calc_deviation.py:31-34 (and cold_disk_planet)
+
+
+def run_cold_disk(lib_run, lib_host, planet, max_snapshots=None):
+    """test/cold_disk(_planet)/setup.yml through the ABI with the driver's circular-orbit stand-in for the N-body
+    system.  Returns a dict: hydro steps, the criterion of calc_deviation.py:22-34 -- max |<T>_phi(last) /
+    <T>_phi(first) - 1| -- after every snapshot, and how non-axisymmetric the final density is."""
+    from fargocpt_amd import driver, setups
+    d, bodies = setups.cold_disk(lib_host, planet)
+    orb = driver.CircularOrbits(d, bodies)
+    ctx = driver.make_context(lib_run, d, bodies=orb.at(0.0, 0.0))
+    T0 = ctx.download(B.F_TEMPERATURE).mean(axis=1)
+    devs = []
+    steps = driver.run_to_snapshots(
+        ctx, d, orb, lambda n: devs.append(float(np.max(np.abs(ctx.download(B.F_TEMPERATURE).mean(axis=1) / T0 - 1)))),
+        max_snapshots=max_snapshots)
+    sig = ctx.download(B.F_SIGMA)
+    out = {"grid": [d.nr_global, d.nphi], "steps": steps, "deviation_per_snapshot": devs,
+           "sigma_nonaxisymmetry": float(np.max(np.abs(sig / sig.mean(axis=1, keepdims=True) - 1)))}
+    ctx.close()
+    return out

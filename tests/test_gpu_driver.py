@@ -99,6 +99,35 @@ def test_steady_state_accretion_setup_file(tmp_path, product):
     assert pairs[100, 1] == pytest.approx(gold["massflow_code_units_at_interface_100"], rel=1e-9)
 
 
+@pytest.mark.parametrize("setup,key,nsnap", [("cold_disk.yml", "cold_disk", 20), ("cold_disk_planet.yml", "cold_disk_planet", 10)])
+def test_cold_disk_setup_files(tmp_path, setup, key, nsnap):
+    """test/cold_disk/setup.yml and test/cold_disk_planet/setup.yml (cps grid key, l0 = 30 au, planet with mass
+    ramp-up on its circular orbit + indirect term) through the driver, checked as calc_deviation.py:22-60 does:
+    dimensions.dat, snapshots/list.txt, units.yml and the Temperature.dat files; threshold 0.1.  The deviation and the
+    step count equal the oracle's run of the same setup."""
+    import json
+    import yaml
+    out = _run(tmp_path, setup, "cold")
+    gold = json.load(open(os.path.join(GOLDEN, "oracle_reference_runs.json")))[key]
+    Nr, Naz = np.genfromtxt(out + "dimensions.dat", usecols=(4, 5), unpack=True, dtype=int)
+    assert [int(Nr), int(Naz)] == gold["grid"]
+    Ns = np.genfromtxt(out + "snapshots/list.txt", dtype=int)
+    assert list(Ns) == list(range(nsnap + 1))
+    tempunit = yaml.safe_load(open(out + "units.yml"))["temperature"]["cgs value"]
+    assert abs(tempunit / (1.0756431684186062e+05 / 30.0) - 1) < 1e-6   # l0 = 30 au
+    prof = {n: (tempunit * np.fromfile(out + f"snapshots/{n}/Temperature.dat").reshape(Nr, Naz)).mean(axis=1) for n in (Ns[0], Ns[-1])}
+    dev = np.max(np.abs(prof[Ns[-1]] / prof[Ns[0]] - 1))
+    assert dev < 0.1
+    assert dev == pytest.approx(gold["deviation_per_snapshot"][-1], rel=1e-4)
+    assert _misc(out + f"snapshots/{nsnap}/misc.bin")["n_iter"] == gold["steps"]
+    sig = np.fromfile(out + f"snapshots/{nsnap}/Sigma.dat").reshape(Nr, Naz)
+    nonaxi = np.max(np.abs(sig / sig.mean(axis=1, keepdims=True) - 1))
+    if key == "cold_disk_planet":
+        assert nonaxi == pytest.approx(gold["sigma_nonaxisymmetry"], rel=1e-3)
+    else:
+        assert nonaxi < 1e-9
+
+
 def test_spreading_ring_setup_file(tmp_path):
     out = _run(tmp_path, "spreading_ring.yml", "ring")
     nr, naz = np.genfromtxt(out + "dimensions.dat", usecols=(4, 5), unpack=True, dtype=int)

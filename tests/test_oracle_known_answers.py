@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from fargocpt_amd import binding as B, driver, setups
-from tests.known_answers import (GOLDEN, SHOCKTUBE_THRESHOLDS, SPREADING_RING_THRESHOLD, STEADY_ACCRETION_THRESHOLD,
+from tests.known_answers import (COLD_DISK_THRESHOLD, run_cold_disk, GOLDEN, SHOCKTUBE_THRESHOLDS, SPREADING_RING_THRESHOLD, STEADY_ACCRETION_THRESHOLD,
                                  run_steady_accretion, shocktube_deviations, spreading_ring_deviation,
                                  steady_accretion_deviation)
 
@@ -73,6 +73,39 @@ def test_steady_state_accretion_reference_criterion(product, oracle):
     g = GOLD["steady_state_accretion_198x1"]
     assert steps == g["steps"]
     assert dev == pytest.approx(g["max_rel_deviation"], rel=1e-6)
+
+
+def test_cold_disk_reference_criterion(product, oracle):
+    """test/cold_disk (setup.yml + calc_deviation.py:22-34): an inviscid ideal-gas power-law disk without heating or
+    cooling keeps its azimuthally averaged temperature profile to 10 % over 20 orbits (97 x 376 cells from cps = 3,
+    l0 = 30 au).  "This test fails when the energy update due to compression heating is performed before the
+    velocity updates from the source terms" (its readme): pins the order of the source step for the energy
+    equation."""
+    res = run_cold_disk(oracle, product, planet=False)
+    g = GOLD["cold_disk"]
+    assert res["grid"] == g["grid"] == [97, 376] and res["steps"] == g["steps"]
+    assert len(res["deviation_per_snapshot"]) == 20
+    assert res["deviation_per_snapshot"][-1] < COLD_DISK_THRESHOLD
+    assert res["deviation_per_snapshot"][-1] == pytest.approx(g["deviation_per_snapshot"][-1], rel=1e-6)
+    assert res["sigma_nonaxisymmetry"] < 1e-10   # stays axisymmetric
+
+
+def test_cold_disk_planet_reference_criterion(product, oracle):
+    """test/cold_disk_planet: the same disk with a 2e-5 planet on a circular orbit (mass ramped up over 10 orbits,
+    indirect term of the star-centred frame), TW artificial viscosity with dissipation: the one reference-held
+    criterion on a NON-axisymmetric flow (spiral wake: Sigma varies by 13 % along a ring).  The full 100 orbits
+    (14 000 steps, ~1 min on the oracle) are recorded in tests/golden/oracle_reference_runs.json by
+    make_oracle_golden.py and must meet the reference's threshold; the first snapshot interval (10 orbits) is
+    re-run here and must reproduce the recorded run."""
+    full, first = GOLD["cold_disk_planet"], GOLD["cold_disk_planet_first_snapshot"]
+    assert len(full["deviation_per_snapshot"]) == 10 and full["steps"] == 14000
+    assert max(full["deviation_per_snapshot"]) < COLD_DISK_THRESHOLD
+    assert full["sigma_nonaxisymmetry"] > 0.05
+    res = run_cold_disk(oracle, product, planet=True, max_snapshots=1)
+    assert res["steps"] == first["steps"]
+    assert res["deviation_per_snapshot"][0] == pytest.approx(first["deviation_per_snapshot"][0], rel=1e-6)
+    assert res["deviation_per_snapshot"][0] == pytest.approx(full["deviation_per_snapshot"][0], rel=1e-6)
+    assert res["sigma_nonaxisymmetry"] == pytest.approx(first["sigma_nonaxisymmetry"], rel=1e-6)
 
 
 def test_mass_conservation_closed_box(product, oracle):
