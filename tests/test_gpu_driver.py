@@ -114,7 +114,8 @@ def test_cold_disk_setup_files(tmp_path, setup, key, nsnap):
     Ns = np.genfromtxt(out + "snapshots/list.txt", dtype=int)
     assert list(Ns) == list(range(nsnap + 1))
     tempunit = yaml.safe_load(open(out + "units.yml"))["temperature"]["cgs value"]
-    assert abs(tempunit / (1.0756431684186062e+05 / 30.0) - 1) < 1e-6   # l0 = 30 au
+    from fargocpt_amd import setups
+    assert abs(tempunit / (setups.TEMP0_K / 30.0) - 1) < 1e-12   # l0 = 30 au
     prof = {n: (tempunit * np.fromfile(out + f"snapshots/{n}/Temperature.dat").reshape(Nr, Naz)).mean(axis=1) for n in (Ns[0], Ns[-1])}
     dev = np.max(np.abs(prof[Ns[-1]] / prof[Ns[0]] - 1))
     assert dev < 0.1
