@@ -67,6 +67,16 @@ struct fcpt_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t e_packed = nullptr, e_received = nullptr;
     int device = 0; // HIP device the context was created on
+    // fcpt_run_steps on launch-bound grids: a captured hipGraph of `graph_cycle` consecutive steps (the out-of-place
+    // transport swaps grid pointers, so the launch arguments repeat with period 2), replayed while the host-side state
+    // that decided the launches (the whole Dev view, the lazy-evaluation flags) is what it was at capture
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    hipStream_t capture_stream = nullptr;
+    int graph_cycle = 0;
+    bool graph_failed = false;
+    Dev graph_P;
+    unsigned graph_flags = 0;
 };
 
 #define DOB_ROWS_HOST 8 /* = DOB_ROWS of k_disk_on_body */
@@ -199,6 +209,17 @@ DampRange damp_range(const fcpt_ctx *c, int is_vector, int type, int outer)
         r.tau = d.damping_time_factor * 2.0 * M_PI / omega_k(d.damping_time_radius_outer);
     }
     return r;
+}
+
+void drop_graph(fcpt_ctx *c)
+{
+    if (c->graph_exec)
+        (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph)
+        (void)hipGraphDestroy(c->graph);
+    c->graph_exec = nullptr;
+    c->graph = nullptr;
+    c->graph_cycle = 0;
 }
 
 // the caller's stream waits for the interior transport forked by fcpt_step_device_begin
@@ -947,6 +968,9 @@ int fcpt_destroy(fcpt_ctx *c)
     if (!c)
         return FCPT_OK;
     (void)fcpt_comm_destroy(c);
+    drop_graph(c);
+    if (c->capture_stream)
+        (void)hipStreamDestroy(c->capture_stream);
     for (void *p : c->allocs)
         (void)hipFree(p);
     if (c->h_clk)
@@ -1667,6 +1691,77 @@ int fcpt_profile_stop(fcpt_ctx *c, double *ms_total, int64_t *launches)
     return FCPT_OK;
 }
 
+} // extern "C"
+namespace {
+unsigned launch_flags(const fcpt_ctx *c)
+{
+    return (c->potential_valid ? 1u : 0u) | (c->pressure_valid ? 2u : 0u) | (c->stepped ? 4u : 0u) |
+           (c->cfl_interior ? 8u : 0u) | (c->kick_energy_b ? 16u : 0u) | (c->fused_source ? 32u : 0u) |
+           (c->march_source ? 64u : 0u) | (c->has_mid ? 128u : 0u) | (c->join_pending ? 256u : 0u) |
+           ((unsigned)c->src_parts << 12);
+}
+bool graph_wanted(const fcpt_ctx *c)
+{
+    if (c->profiling || c->graph_failed || c->comm)
+        return false;
+    if (c->P.opt.graph_steps >= 0)
+        return c->P.opt.graph_steps != 0;
+    // launch-bound grids: the kernels of a step are shorter than the host's launch calls
+    return (long long)c->P.nr * c->P.nphi <= 131072;
+}
+// one iteration of the device-resident loop: CFL reduction -> policy kernel -> step -> post
+void enqueue_device_step(fcpt_ctx *c)
+{
+    enqueue_cfl(c, 1);
+    enqueue_step(c, true, 0.0, c->d.cfl <= 0.8);
+    enqueue_post(c);
+}
+// capture `cycle` steps; true if the host-side state is back where it started (the graph can be replayed)
+bool capture_graph(fcpt_ctx *c, int cycle)
+{
+    if (!c->capture_stream && hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess)
+        return false;
+    const Dev P0 = c->P;
+    const unsigned f0 = launch_flags(c);
+    hipStream_t user = c->stream;
+    c->stream = c->capture_stream;
+    bool ok = hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        for (int n = 0; n < cycle; ++n)
+            enqueue_device_step(c);
+        hipGraph_t g = nullptr;
+        ok = hipStreamEndCapture(c->capture_stream, &g) == hipSuccess && g != nullptr;
+        c->graph = g;
+    }
+    c->stream = user;
+    (void)hipGetLastError();
+    const bool periodic = std::memcmp(&P0, &c->P, sizeof(Dev)) == 0 && f0 == launch_flags(c);
+    if (ok && periodic)
+        ok = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) == hipSuccess;
+    if (!ok || !periodic) {
+        // nothing was executed during the capture: put the host-side view back and step without a graph
+        c->P = P0;
+        c->grid[FCPT_F_SIGMA] = c->P.sigma;
+        c->grid[FCPT_F_VRAD] = c->P.vrad;
+        c->grid[FCPT_F_VAZI] = c->P.vazi;
+        c->grid[FCPT_F_ENERGY] = c->P.energy;
+        c->potential_valid = f0 & 1u;
+        c->pressure_valid = f0 & 2u;
+        c->stepped = f0 & 4u;
+        c->cfl_interior = f0 & 8u;
+        c->kick_energy_b = f0 & 16u;
+        c->src_parts = (int)(f0 >> 12);
+        drop_graph(c);
+        return false;
+    }
+    c->graph_cycle = cycle;
+    c->graph_P = c->P;
+    c->graph_flags = f0;
+    return true;
+}
+} // namespace
+extern "C" {
+
 // sim::run's loop (simulation.cpp:515-553) for a single slab.
 int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
 {
@@ -1722,11 +1817,23 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
         }
     } else if (!snap) {
         // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
-        for (; n < nsteps; ++n) {
-            enqueue_cfl(c, 1); // CFL + CalculateTimeStep policy on the device
-            enqueue_step(c, true, 0.0, c->d.cfl <= 0.8); // dt: the policy kernel of launch_cfl just above
-            enqueue_post(c);
+        if (graph_wanted(c) && nsteps >= 8) {
+            join_side(c);
+            if (c->graph_exec && (std::memcmp(&c->graph_P, &c->P, sizeof(Dev)) != 0 || c->graph_flags != launch_flags(c)))
+                drop_graph(c); // bodies, options, pointers or lazy flags changed since the capture
+            if (!c->graph_exec) {
+                for (; n < 2; ++n) // the lazily evaluated grids settle within two steps
+                    enqueue_device_step(c);
+                if (!capture_graph(c, 2) && !capture_graph(c, 4))
+                    c->graph_failed = true;
+            }
+            if (c->graph_exec) {
+                for (; n + c->graph_cycle <= nsteps; n += c->graph_cycle)
+                    HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+            }
         }
+        for (; n < nsteps; ++n)
+            enqueue_device_step(c);
         HIPCHK(hipGetLastError());
     } else {
         const double t_final = (double)c->d.nsnapshots * c->d.nmonitor * c->d.monitor_timestep;

@@ -113,6 +113,40 @@ void launch_source_fused(const Dev &P, hipStream_t st)
     LAUNCH2D(KID_SRC_FUSED, k_src_fused, P.nr + 1, P);
     LAUNCH2D(KID_AV_FUSED, k_av_fused, P.nr + 1, P);
 }
+// Rings per marching chunk.  A marching wavefront is a serial chain of (rows + pre-roll) ring iterations; the GPU
+// holds 256 CUs x 4 SIMDs x 4 wavefronts of these kernels at a time.  On grids that fill it several times over the
+// measured optimum is the default (24 rings at 2048 x 4096: the pre-roll of 4-5 rings per chunk against the tail of
+// the last blocks).  Smaller grids have fewer wavefronts than the GPU has slots: there the chain length is the
+// kernel time, so the chunks shrink until the wavefronts fill the slots once (1024 x 3072: 14-15 rings, 128 x 384: 4).
+static int march_rows(int nrows, int tiles, int rows_max, int preroll)
+{
+    const double slots = 4096.0;
+    int best = rows_max;
+    double best_t = 1e300;
+    for (int r = 4; r <= rows_max; ++r) {
+        const double waves = (double)tiles * ((nrows + r - 1) / r);
+        const double t = (r + preroll) * (waves <= slots ? 1.0 : waves / slots);
+        if (t < best_t * (1.0 - 1e-9) || (t <= best_t * (1.0 + 1e-9) && r > best)) {
+            best_t = t;
+            best = r;
+        }
+    }
+    return best;
+}
+static int source_rows(const Dev &P)
+{
+    if (P.opt.source_rows > 0)
+        return P.opt.source_rows;
+    return march_rows(P.nr + 1, (P.nphi + MARCH_VALID - 1) / MARCH_VALID, 24, 4);
+}
+static int transport_rows(const Dev &P)
+{
+    if (P.opt.transport_rows > 0)
+        return P.opt.transport_rows;
+    const int CF = 1; // cells per lane of the default kernel
+    const int tstride = 64 * CF - (TfHalo<1>::lo + TfHalo<1>::hi);
+    return march_rows(P.nr, (P.nphi + tstride - 1) / tstride, TF_ROWS, 5);
+}
 // whole source step in one marching pass (isothermal, Nphi >= 128); returns false if not applicable
 int launch_source_march(const Dev &P, hipStream_t st)
 {
@@ -121,7 +155,7 @@ int launch_source_march(const Dev &P, hipStream_t st)
     if (P.adiabatic) {
         if (P.opt.march_source_adi == 0)
             return 0;
-        const int rows = P.opt.source_rows > 0 ? P.opt.source_rows : 24;
+        const int rows = source_rows(P);
         const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
         const int chunks = (P.nr + 1 + rows - 1) / rows;
         const dim3 grid((segs * chunks + 3) / 4), block(256);
@@ -142,7 +176,7 @@ int launch_source_march(const Dev &P, hipStream_t st)
         return -segs; // marched, no ring sums
     }
     // measured at 2048x4096: 16 / 24 / 32 / 48 / 64 rings -> 0.133 / 0.132 / 0.141 / 0.152 / 0.188 ms
-    const int rows = P.opt.source_rows > 0 ? P.opt.source_rows : 24;
+    const int rows = source_rows(P);
     const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
     // per-segment ring sums of v_phi, so that the transport's k_ring_mean reads 70 partials per ring
     // instead of the ring itself
@@ -314,7 +348,8 @@ bool transport_can_split(const Dev &P, bool shear_safe)
         return false; // tuning runs keep the one-launch form
     if (P.opt.transport_split == 0)
         return false;
-    const int chunks = (P.nr + TF_ROWS - 1) / TF_ROWS, c_lo = (P.nr - 2 * FCPT_OVERLAP) / TF_ROWS;
+    const int rows = transport_rows(P);
+    const int chunks = (P.nr + rows - 1) / rows, c_lo = (P.nr - 2 * FCPT_OVERLAP) / rows;
     return c_lo >= 2 && c_lo < chunks;
 }
 // part: TRANSPORT_ALL, or -- for slabs with neighbours, when transport_can_split() -- launch_shift_means, then
@@ -339,7 +374,7 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         Wm.vazi = P.vazi == W.vazi ? W.vazi_b : W.vazi;
         if (part == TRANSPORT_ALL)
             launch_shift_means(P, st); // else: the caller queued it ahead of both parts
-        const int rows = P.opt.transport_rows > 0 ? P.opt.transport_rows : TF_ROWS;
+        const int rows = transport_rows(P);
         const int tstride = 64 * CF - (CF == 2 ? TfHalo<2>::lo + TfHalo<2>::hi : TfHalo<1>::lo + TfHalo<1>::hi);
         const int tiles = (P.nphi + tstride - 1) / tstride;
         const int chunks = (P.nr + rows - 1) / rows;

@@ -642,3 +642,47 @@ def test_massflow_grid(product, oracle, nr, nphi, adiabatic, leapfrog):
     with pytest.raises(B.FcptError, match="FCPT_EINVAL"):
         ctx.download(B.F_MASSFLOW)
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["shocktube_256x4", "ring_128x384", "ideal_48x96", "leapfrog_64x320", "iso_96x512"])
+def test_graph_replay_is_bit_identical(product, case):
+    """fcpt_run_steps replaying a captured hipGraph of two steps (launch-bound grids) against the same loop with
+    plain launches: same bits, same clock -- also across a change of the bodies between two calls, which makes the
+    captured launch arguments stale (the graph must be dropped and captured again)."""
+    from fargocpt_amd import driver
+    bodies = None
+    if case == "shocktube_256x4":
+        d = setups.shocktube(product, 256, 4, "SN")
+        d.first_dt = 1e-6
+    elif case == "ring_128x384":
+        d = setups.spreading_ring(product, 128, 384)
+        d.first_dt = 1e-3
+    elif case == "ideal_48x96":
+        d = setups.planet_disk(product, 48, 96, adiabatic=True)
+        bodies = setups.jupiter_bodies(d)
+    elif case == "leapfrog_64x320":
+        d = setups.planet_disk(product, 64, 320)
+        d.integrator = B.INTEGRATOR_LEAPFROG
+        bodies = setups.jupiter_bodies(d)
+    else:
+        d = setups.planet_disk(product, 96, 512)
+        bodies = setups.jupiter_bodies(d)
+    out = []
+    for graph in (1, 0):
+        ctx = driver.make_context(product, d, bodies=bodies)
+        ctx.set_option("graph_steps", graph)
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        assert ctx.run_steps(21) == 21          # odd: one plain step behind the replays
+        if bodies is not None:
+            x, y, m = bodies
+            ctx.set_bodies([x[0], 0.0], [y[0], 1.0], m)   # the planet a quarter orbit further
+        assert ctx.run_steps(12) == 12
+        assert ctx.run_steps(3) == 3            # too short for a graph: plain launches
+        c = ctx.clock
+        out.append((ctx.state(), (c.time, c.last_dt, c.n_hydro_iter)))
+        ctx.close()
+    assert out[0][1] == out[1][1]
+    assert out[0][1][2] == 36
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
