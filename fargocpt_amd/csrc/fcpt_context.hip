@@ -98,6 +98,7 @@ void options_from_environment(Options &o)
     o.transport_fused = o.transport_rows = o.source_rows = o.theta_rows = -1;
     o.transport_fallback = o.transport_split = o.fused_source = o.march_source = o.march_source_adi = 1;
     o.theta_march = o.theta_fused = o.cfl_rings = o.cfl_split = o.source_ring_parts = o.fused_damping = 1;
+    o.inline_potential = 1;
     o.comm_overlap = 0;
     o.comm_loopback = 0;
     o.graph_steps = -1;
@@ -242,6 +243,7 @@ void apply_options(fcpt_ctx *c, bool at_create = true)
     const bool adi_march =
         c->P.adiabatic && c->fused_source && c->march_source && c->P.nphi >= 128 && o.march_source_adi != 0;
     c->P.lazy_derived = adi_march ? 1 : 0;
+    c->P.inline_potential = (adi_march && !c->P.leapfrog && o.inline_potential != 0) ? 1 : 0;
     c->P.damp_in_step = (c->damp_foldable && o.fused_damping != 0) ? 1 : 0;
     c->cfl_interior = false;
     c->potential_valid = false;
@@ -371,6 +373,10 @@ void enqueue_potential(fcpt_ctx *c, bool midstep)
         }
         launch_potential(M, c->stream);
         c->potential_valid = false; // the grid now holds the mid-step potential
+        return;
+    }
+    if (P.inline_potential) { // k_source_march_adi evaluates it ring by ring; the grid is only filled on request
+        c->potential_valid = false;
         return;
     }
     if (P.adiabatic || !c->potential_valid) {
@@ -738,6 +744,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     AL(rmpB, ns) AL(rmmB, ns) AL(lpB, ns) AL(lmB, ns) AL(sigB, ns) AL(eB, ns)
     AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1) AL(shift_jump, 1)
     AL(cfl_part, (size_t)(nr + 256) * (size_t)((nphi + 255) / 256 + 1))
+    AL(cfl_tickets, 32)
     P.ring_pstride = nphi / 32 + 4;
     AL(ring_part, (size_t)nr * P.ring_pstride)
     P.stabilize = d->stabilize_viscosity;
@@ -1087,6 +1094,11 @@ int fcpt_download(fcpt_ctx *c, int32_t f, double *host)
     if (f == FCPT_F_PRESSURE || (c->P.adiabatic && (f == FCPT_F_SOUNDSPEED || f == FCPT_F_SCALE_HEIGHT ||
                                                      f == FCPT_F_VISCOSITY || f == FCPT_F_TEMPERATURE)))
         ensure_pressure(c);
+    if (f == FCPT_F_POTENTIAL && !c->potential_valid) {
+        // evaluated inside the source march (ideal EOS): the grid on request, from the current state and bodies
+        launch_potential(c->P, c->stream);
+        c->potential_valid = !c->P.adiabatic;
+    }
     HIPCHK(hipMemcpyAsync(host, c->grid[f], grid_count(c, f) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return FCPT_OK;

@@ -136,6 +136,7 @@ struct Options {
     int cfl_split;          // fcpt_cfl_begin evaluates the interior rings ahead of the ghost exchange
     int source_ring_parts;  // 0: the transport's ring mean re-reads v_phi
     int fused_damping;      // 0: the wave damping as separate kernels in the final boundary call
+    int inline_potential;   // 0: ideal EOS: k_potential every step instead of the evaluation inside k_source_march_adi
     int comm_overlap;       // fcpt_exchange: transfers on the library's communication stream under the interior CFL
     int comm_loopback;      // rehearsal on one GPU: both "neighbours" of the slab are the slab itself
     int graph_steps;        // fcpt_run_steps: replay a captured hipGraph of one step (launch-bound narrow grids)
@@ -143,7 +144,7 @@ struct Options {
 #define FCPT_OPTION_NAMES                                                                                        \
     X(transport_fused) X(transport_rows) X(source_rows) X(theta_rows) X(transport_fallback) X(transport_split)    \
     X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_split)   \
-    X(source_ring_parts) X(fused_damping) X(comm_overlap) X(comm_loopback) X(graph_steps)
+    X(source_ring_parts) X(fused_damping) X(inline_potential) X(comm_overlap) X(comm_loopback) X(graph_steps)
 
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.
 struct Dev {
@@ -162,6 +163,7 @@ struct Dev {
     CArr g_inv_omk;  // 1 / Omega_K(Rmed[i])
     int lazy_derived; // ideal EOS + marching source step: c_s, H, nu, T, P are formed in registers where needed,
                       // the grids are only materialised for callers that ask for them
+    int inline_potential; // ... and the potential of the Euler step inside k_source_march_adi
     // state
     double *sigma, *vrad, *vazi, *energy;
     double *vrad_b, *vazi_b; // intermediate velocities of the fused source step
@@ -198,6 +200,7 @@ struct Dev {
     int damp_in_step;
     CArrI nshift_c;
     double *cfl_part; // per-block maxima of the CFL reduction
+    int *cfl_tickets; // 1 + CFL_TICKET_LANES counters of the "last workgroup folds" scheme (zero between launches)
     // per-ring partial sums of v_phi left by k_source_march for the transport's ring mean
     // (pstride entries per ring, src_ring_nparts of them valid, 0 = not available)
     double *ring_part;

@@ -86,6 +86,8 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
     if (tid == 0)
         part[blockIdx.y * gridDim.x + blockIdx.x] = dmax(dmax(s_w[0], s_w[1]), dmax(s_w[2], s_w[3]));
 }
+__device__ __forceinline__ void cfl_fold(const Dev &P, const double *part, int nparts, int apply_policy);
+__device__ __forceinline__ bool cfl_last_workgroup(int *tickets, int b, int nb);
 // Ring mean and per-cell limits in one pass: a block owns a ring, keeps its v_phi in registers
 // (CFL_MAXP pairs per thread), sums them (<v_phi>, cfl.cpp:196-205), then evaluates the cells of
 // the ring against that mean (:222-330) -- v_phi is read once instead of once by k_ring_mean and
@@ -93,7 +95,9 @@ template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
 #define CFL_MAXP 8 // pairs of cells per thread (Nphi <= 4096); 16 for rings up to 8192 cells
 // The launch covers rings [r1, r1+n1) and [r2, r2+n2): all of them in one go, or (slabs with neighbours) the
 // interior while the ghost rings are on the wire and the rings next to them after the unpack (fcpt_cfl_begin).
-template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part, int r1, int n1, int r2)
+// finalize: 0 = partial maxima only (the interior rings ahead of the ghost exchange), 1 + apply_policy = the last
+// workgroup also folds them (cfl_fold over all nr rings)
+template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part, int r1, int n1, int r2, int finalize)
 {
     const int b = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
     const int i = b < n1 ? r1 + b : r2 + (b - n1);
@@ -198,8 +202,12 @@ template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings
     __syncthreads();
     if (t == 0)
         part[i] = dmax(dmax(s_m[0], s_m[1]), dmax(s_m[2], s_m[3]));
+    if (finalize && cfl_last_workgroup(P.cfl_tickets, blockIdx.x, gridDim.x))
+        cfl_fold(P, part, P.nr, finalize - 1);
 }
-__global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *part, int nparts, int apply_policy)
+// The last step of the reduction by one workgroup: fold the partial maxima, add the FARGO shear limit, leave the
+// result in the device clock (and apply the CalculateTimeStep policy for device-resident loops).
+__device__ __forceinline__ void cfl_fold(const Dev &P, const double *part, int nparts, int apply_policy)
 {
     double smax = 0.0;
     for (int n = threadIdx.x; n < nparts; n += blockDim.x)
@@ -239,6 +247,38 @@ __global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *p
             P.clk->dt = rv;
         }
     }
+}
+__global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *part, int nparts, int apply_policy)
+{
+    cfl_fold(P, part, nparts, apply_policy);
+}
+// "Last workgroup folds": every workgroup of k_cfl_rings takes a ticket after its partial maximum is in memory, the
+// one that draws the last ticket runs cfl_fold -- no separate launch for the final fold.  Two levels of tickets
+// (CFL_TICKET_LANES counters, then one) keep the same-address atomics, ~10 ns each on this GPU, off the critical path.
+#define CFL_TICKET_LANES 16
+__device__ __forceinline__ bool cfl_last_workgroup(int *tickets, int b, int nb)
+{
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        const int lane = b % CFL_TICKET_LANES;
+        const int in_lane = nb / CFL_TICKET_LANES + (lane < nb % CFL_TICKET_LANES ? 1 : 0);
+        const int lanes_used = nb < CFL_TICKET_LANES ? nb : CFL_TICKET_LANES;
+        int last = 0;
+        // release: this workgroup's partial result (written by this thread) is visible before the ticket
+        if (__hip_atomic_fetch_add(tickets + 1 + lane, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == in_lane - 1) {
+            tickets[1 + lane] = 0;
+            if (__hip_atomic_fetch_add(tickets, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == lanes_used - 1) {
+                tickets[0] = 0; // ready for the next launch (stream order)
+                last = 1;
+            }
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    const bool last = s_last != 0;
+    if (last)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the other workgroups' partials, not this CU's cache
+    return last;
 }
 
 // ---------------------------------------------------------------------------

@@ -160,11 +160,18 @@ int launch_source_march(const Dev &P, hipStream_t st)
         const int chunks = (P.nr + 1 + rows - 1) / rows;
         const dim3 grid((segs * chunks + 3) / 4), block(256);
         const bool cool = P.cooling_surface != 0 || P.cooling_beta != 0 || P.heating_star != 0;
-#define ADIK(AV_)                                                                                 \
-    if (cool)                                                                                     \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, true>), grid, block, P, segs, rows);  \
-    else                                                                                          \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, false>), grid, block, P, segs, rows)
+        const int ring_sums = segs <= P.ring_pstride && P.opt.source_ring_parts != 0;
+#define ADIKP(AV_, POT_)                                                                                      \
+    if (cool)                                                                                                 \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, true, POT_>), grid, block, P, segs, rows, ring_sums); \
+    else                                                                                                      \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, false, POT_>), grid, block, P, segs, rows, ring_sums)
+#define ADIK(AV_)            \
+    if (P.inline_potential) { \
+        ADIKP(AV_, true);    \
+    } else {                 \
+        ADIKP(AV_, false);   \
+    }
         if (P.art_visc == FCPT_ARTVISC_TW) {
             ADIK(1);
         } else if (P.art_visc == FCPT_ARTVISC_SN) {
@@ -173,7 +180,8 @@ int launch_source_march(const Dev &P, hipStream_t st)
             ADIK(0);
         }
 #undef ADIK
-        return -segs; // marched, no ring sums
+#undef ADIKP
+        return ring_sums ? segs : -segs; // < 0: marched, but no ring sums
     }
     // measured at 2048x4096: 16 / 24 / 32 / 48 / 64 rings -> 0.133 / 0.132 / 0.141 / 0.152 / 0.188 ms
     const int rows = source_rows(P);
@@ -350,7 +358,8 @@ bool transport_can_split(const Dev &P, bool shear_safe)
         return false;
     const int rows = transport_rows(P);
     const int chunks = (P.nr + rows - 1) / rows, c_lo = (P.nr - 2 * FCPT_OVERLAP) / rows;
-    return c_lo >= 2 && c_lo < chunks;
+    const int lead = (2 * FCPT_OVERLAP + rows - 1) / rows; // chunks that hold rows [0, 14)
+    return c_lo > lead && c_lo < chunks;
 }
 // part: TRANSPORT_ALL, or -- for slabs with neighbours, when transport_can_split() -- launch_shift_means, then
 // TRANSPORT_INTERIOR on a side stream and TRANSPORT_EDGES (the chunks holding the rings a neighbour receives, rows
@@ -386,11 +395,12 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         // for flows known to be benign; a violation is then reported as FCPT_ESHEAR.
         const int fallback = P.opt.transport_fallback != 0;
         TfChunks ch = {chunks, chunks, 0, 1};
-        const int c_lo = (P.nr - 2 * FCPT_OVERLAP) / rows; // first chunk of the outer tail
+        const int c_lo = (P.nr - 2 * FCPT_OVERLAP) / rows;    // first chunk of the outer tail (holds row nr - 14)
+        const int lead = (2 * FCPT_OVERLAP + rows - 1) / rows; // chunks that hold rows [0, 14)
         if (part == TRANSPORT_EDGES)
-            ch = TfChunks{1 + (chunks - c_lo), 1, c_lo - 1, 1};
+            ch = TfChunks{lead + (chunks - c_lo), lead, c_lo - lead, 1};
         else if (part == TRANSPORT_INTERIOR)
-            ch = TfChunks{c_lo - 1, 0, 1, 0};
+            ch = TfChunks{c_lo - lead, 0, lead, 0};
         res.split = part != TRANSPORT_ALL;
         const dim3 grid((ch.count * tiles + 3) / 4), block(256);
 #define TFK(CC, AA, DD)                                                                                             \
@@ -503,36 +513,36 @@ bool cfl_by_rings(const Dev &P)
     return (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 1024 * CFL_MAXP && (!P.adiabatic || P.lazy_derived) &&
            P.stabilize != 2 && P.opt.cfl_rings != 0;
 }
-static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, hipStream_t st)
+static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, int finalize, hipStream_t st)
 {
     if (n1 + n2 <= 0)
         return;
     const bool wide = P.nphi > 512 * CFL_MAXP;
     if (P.adiabatic && wide)
-        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<true, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<true, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
     else if (P.adiabatic)
-        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<true, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<true, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
     else if (wide)
-        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<false, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<false, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
     else
-        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<false, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2);
+        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<false, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
 }
 // phase 1 of a split CFL: the interior rings only (returns false when the one-block-per-ring kernel does not apply)
 bool launch_cfl_interior(const Dev &P, hipStream_t st)
 {
     if (!cfl_by_rings(P) || P.nr <= CFL_EDGE_LO + CFL_EDGE_HI)
         return false;
-    launch_cfl_rings(P, CFL_EDGE_LO, P.nr - CFL_EDGE_LO - CFL_EDGE_HI, 0, 0, st);
+    launch_cfl_rings(P, CFL_EDGE_LO, P.nr - CFL_EDGE_LO - CFL_EDGE_HI, 0, 0, 0, st);
     return true;
 }
 void launch_cfl(const Dev &P, int apply_policy, hipStream_t st, bool interior_done)
 {
     if (cfl_by_rings(P)) {
+        // the workgroup that finishes last folds the per-ring maxima (cfl_last_workgroup): one launch
         if (interior_done)
-            launch_cfl_rings(P, 0, CFL_EDGE_LO, P.nr - CFL_EDGE_HI, CFL_EDGE_HI, st);
+            launch_cfl_rings(P, 0, CFL_EDGE_LO, P.nr - CFL_EDGE_HI, CFL_EDGE_HI, 1 + apply_policy, st);
         else
-            launch_cfl_rings(P, 0, P.nr, 0, 0, st);
-        KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
+            launch_cfl_rings(P, 0, P.nr, 0, 0, 1 + apply_policy, st);
         return;
     }
     KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 0, (const double *)nullptr, 0, P.ring_pstride);

@@ -233,8 +233,11 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
 // the final state, as recalculate_derived_disk_quantities does.
 // COOL: the cooling terms of SubStep3 are compiled in (their opacity laws would otherwise cost the
 // common no-cooling case 70 registers: 134 -> 208 VGPRs)
-template <int AV, bool COOL> // AV 0: none, 1: TW, 2: SN
-__global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs, int rows_per_chunk)
+// POT: the potential of ring m is evaluated here (CalculateNbodyPotential, Pframeforce.cpp:21-94, with the
+// smoothing length ThicknessSmoothing * H of the cell, Force.cpp:124-159) instead of read from the grid
+// k_potential would have to refresh every step, because H follows the energy.
+template <int AV, bool COOL, bool POT> // AV 0: none, 1: TW, 2: SN
+__global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs, int rows_per_chunk, int ring_sums)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -273,20 +276,50 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     double vr2_1 = 0, vr2_2 = 0, va2_1 = 0, va2_2 = 0;                      // after artificial viscosity
     double trr_2 = 0, trr_3 = 0, tpp_2 = 0, tpp_3 = 0, trp_1 = 0, trp_2 = 0;
 
+    // k_potential in registers: this lane's column (cos phi_j, sin phi_j) against the bodies
+    const double cosj = POT ? P.cosphi[j] : 0.0, sinj = POT ? P.sinphi[j] : 0.0;
+    const double gg1 = P.gamma * gm1;
+    auto potential_of = [&](int r, double sg, double en) {
+        const double rmed = P.Rmed[r];
+        const double x = rmed * cosj, y = rmed * sinj;
+        const double cs = sqrt(gg1 * en * fast_rcp(sg));
+        const double H = cs * inv_sqrt_gamma * P.g_inv_omk[r];
+        const double smooth = P.thickness_smoothing * H;
+        double pot = 0.0;
+        for (int k = 0; k < P.nbodies; ++k) {
+            const double dx = x - P.bx[k];
+            const double dy = y - P.by[k];
+            const double dist_2 = dx * dx + dy * dy;
+            const double d2s = dist_2 + smooth * smooth;
+            const double inv_d = fast_rsqrt(d2s); // 1 / d_smoothed
+            double klahr = 1.0;
+            const double r_sm = P.brsm[k];
+            if (r_sm > 0.0) {
+                const double d_smoothed = d2s * inv_d;
+                if (d_smoothed < r_sm) {
+                    const double q = d_smoothed / r_sm;
+                    klahr = ((q * q) * (q * q) - 2.0 * (q * q * q) + 2.0 * d_smoothed / r_sm);
+                }
+            }
+            pot += -P.G * P.bm[k] * inv_d * klahr;
+        }
+        pot += -P.indirect_x * x - P.indirect_y * y;
+        return pot;
+    };
     // ring k0-3 is the "previous" ring of the first iteration
     {
         const int r = crow(k0 - 3);
         S_m = P.sigma[IDX(r, j)];
-        F_m = P.potential[IDX(r, j)];
         va0_m = P.vazi[IDX(r, j)];
         e0_m = P.energy[IDX(r, j)];
+        F_m = POT ? potential_of(r, S_m, e0_m) : P.potential[IDX(r, j)];
         Pr_m = gm1 * e0_m;
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
     }
     // software prefetch of the next input ring
     int rn = k0 - 2;
-    double pS = P.sigma[IDX(crow(rn), j)], pF = P.potential[IDX(crow(rn), j)], pE = P.energy[IDX(crow(rn), j)];
+    double pS = P.sigma[IDX(crow(rn), j)], pF = POT ? 0.0 : P.potential[IDX(crow(rn), j)], pE = P.energy[IDX(crow(rn), j)];
     double pVa = P.vazi[IDX(crow(rn), j)], pVr = P.vrad[IDX(vrow(rn), j)];
 
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
@@ -302,11 +335,14 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
         {
             const int r = m + 1;
             pS = P.sigma[IDX(crow(r), j)];
-            pF = P.potential[IDX(crow(r), j)];
+            if (!POT)
+                pF = P.potential[IDX(crow(r), j)];
             pE = P.energy[IDX(crow(r), j)];
             pVa = P.vazi[IDX(crow(r), j)];
             pVr = P.vrad[IDX(vrow(r), j)];
         }
+        if (POT)
+            F_m = potential_of(crow(m), S_m, e0_m);
         Pr_m = gm1 * e0_m;
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
@@ -493,6 +529,11 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
                         if (P.leapfrog)
                             P.scale_height[IDX(k, j)] = H_2;
                     }
+                }
+                if (ring_sums && k < nr) { // this segment's share of sum_j v_phi(k, j) for the transport's <v_phi>
+                    const double part = wave_sum(store_lane ? va3 : 0.0);
+                    if (lane == 63)
+                        P.ring_part[k * P.ring_pstride + seg] = part;
                 }
             }
         }

@@ -79,7 +79,7 @@ enum {
     FCPT_F_SCALE_HEIGHT = 6,
     FCPT_F_VISCOSITY = 7,
     FCPT_F_TEMPERATURE = 8,
-    FCPT_F_POTENTIAL = 9,
+    FCPT_F_POTENTIAL = 9, /* ideal EOS, Euler: evaluated inside the source step; a download fills the grid from the current state */
     FCPT_F_SIGMA0 = 10,
     FCPT_F_VRAD0 = 11, /* (Nr+1) x Nphi */
     FCPT_F_VAZI0 = 12,
@@ -300,8 +300,8 @@ int fcpt_synchronize(fcpt_ctx *ctx);
  * environment variables FCPT_<NAME> only provide the defaults read once in fcpt_create; no launch reads the
  * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows,
  * source_rows, theta_rows, transport_fallback, transport_split, fused_source, march_source, march_source_adi,
- * theta_march, theta_fused, cfl_rings, cfl_split, source_ring_parts, fused_damping, comm_overlap, comm_loopback,
- * graph_steps.
+ * theta_march, theta_fused, cfl_rings, cfl_split, source_ring_parts, fused_damping, inline_potential, comm_overlap,
+ * comm_loopback, graph_steps.
  * FCPT_EINVAL for an unknown name.  (The reference has no counterpart: its variants are compile-time.) */
 int fcpt_set_option(fcpt_ctx *ctx, const char *name, int32_t value);
 int fcpt_get_option(const fcpt_ctx *ctx, const char *name, int32_t *value);
