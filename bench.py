@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NR_PER_GPU, NPHI = 2048, 4096
+PARITY_STEPS = 40  # steps of the bench workload that the oracle repeats on the CPU (~10 s on 16 host threads)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # FP64 vector issue: 256 CUs x 4 SIMDs, one wave instruction per 4 cycles per SIMD for FP64 FMA/MUL/ADD
 # (78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz), MI355X_MICROARCH.md
@@ -231,6 +232,18 @@ def main():
 
     pre_loop()
 
+    # ---- parity leg, device half: the same workload on a second context, PARITY_STEPS steps from the same initial
+    # state; the oracle repeats them on the host cores after the timed region and the two end states are compared
+    # (cpu_baseline.parity_max_rel).  Queued here, ahead of the warm-up: the timed region then starts on a GPU
+    # that has been busy for ~20 ms instead of ~2 ms (see ms_per_step_blocks for what that is worth).
+    parity_ctx = None
+    if world == 1 and not rehearse and not args.no_cpu_baseline:
+        parity_ctx = driver.make_context(lib, d, fields=fields, radii=radii, bodies=bodies)
+        parity_ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        for _ in range(2):
+            parity_ctx.calculate_timestep(parity_ctx.cfl())
+        parity_ctx.run_steps(PARITY_STEPS)
+
     # ---- warm-up, with a per-kernel calibration pass to find the dominant kernel --
     cal = min(3, max(1, args.warmup))
     ctx.profile_start(None, max_launches=64 * cal)
@@ -290,7 +303,7 @@ def main():
         pmc = load_pmc(f"{args.nr}x{args.nphi}", "ideal" if adi else "isothermal")
         traffic = pmc.get("hbm_bytes_per_launch", {}).get(dominant)
         valu_busy = pmc.get("valu_busy", {}).get(dominant)
-        wave_insts = pmc.get("valu_wave_insts_per_launch", {}).get(dominant)
+        wave_insts = pmc.get("valu_insts_per_launch", {}).get(dominant)
         # ALGORITHMIC bytes per launch: SURVEY.md 8(d)'s per-cell figure of the passes this kernel stands for
         model = MODEL_PASSES.get(dominant)
         doubles = model[1][adi] if model else OWN_DOUBLES.get(dominant, (0, 0))[adi]
@@ -325,7 +338,10 @@ def main():
             # right after it (clock ramp / settling)
             "untimed_steps_before_timed_region": args.warmup,
             "untimed_other": "2 CFL + CalculateTimeStep calls of sim::init; the first min(3, W) warm-up steps carry "
-                             "HIP-event pairs around every kernel (calibration of the dominant kernel)",
+                             "HIP-event pairs around every kernel (calibration of the dominant kernel)"
+                             + (f"; before the warm-up, {PARITY_STEPS} steps of the same workload on a second context "
+                                "(device half of cpu_baseline's parity check), queued on the same stream"
+                                if parity_ctx is not None else ""),
             "ms_per_step_blocks": blocks,
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -349,8 +365,10 @@ def main():
         ctx.close()
         if world == 1 and not rehearse and not args.no_configs:
             out["configs"] = config_table(lib, args)
-        if world == 1 and not rehearse and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(lib, d, fields, radii, bodies)
+        if parity_ctx is not None:
+            hip_state = parity_ctx.state()
+            parity_ctx.close()
+            out["cpu_baseline"] = cpu_baseline(d, fields, radii, bodies, hip_state)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     else:
         ctx.close()
@@ -453,11 +471,11 @@ def config_table(lib, args):
     return rows
 
 
-def cpu_baseline(lib, d, fields, radii, bodies):
+def cpu_baseline(d, fields, radii, bodies, hip_state):
     """The CPU oracle (oracle/fargo_oracle.c, a C+OpenMP restatement of the reference loops) timed on this
     box's host cores on a bounded sample of the same workload -- and used as the checker of the bench
-    workload itself: the HIP path repeats the same n steps from the same initial state and the two end
-    states are compared (parity_max_rel, the bar is 1e-10)."""
+    workload itself: `hip_state` is what the HIP path made of the same initial state in the same
+    PARITY_STEPS steps; the two end states are compared (parity_max_rel, the bar is 1e-10)."""
     import ctypes
     import numpy as np
     from fargocpt_amd import binding as B, driver
@@ -471,27 +489,17 @@ def cpu_baseline(lib, d, fields, radii, bodies):
     for _ in range(2):
         ctx.calculate_timestep(ctx.cfl())
     t0 = time.perf_counter()
-    n = 0
+    n = PARITY_STEPS
     el_first = None
-    while True:
+    for k in range(n):
         ctx.run_steps(1)
-        n += 1
-        el = time.perf_counter() - t0
         if el_first is None:
-            el_first = el  # the first step pages the grids in: not part of the rate
-        if el > 14.0 or n >= 41:
-            break
+            el_first = time.perf_counter() - t0  # the first step pages the grids in: not part of the rate
+    el = time.perf_counter() - t0
     cells = d.nr_global * d.nphi
-    rate = cells * (n - 1) / (el - el_first) if n > 1 else cells / el
+    rate = cells * (n - 1) / (el - el_first)
     ref_state = ctx.state()
     ctx.close()
-
-    hip = driver.make_context(lib, d, fields=fields, radii=radii, bodies=bodies)
-    for _ in range(2):
-        hip.calculate_timestep(hip.cfl())
-    hip.run_steps(n)
-    hip_state = hip.state()
-    hip.close()
     parity = {}
     for k, b in ref_state.items():
         a = hip_state[k]

@@ -538,11 +538,14 @@ bool launch_cfl_interior(const Dev &P, hipStream_t st)
 void launch_cfl(const Dev &P, int apply_policy, hipStream_t st, bool interior_done)
 {
     if (cfl_by_rings(P)) {
-        // the workgroup that finishes last folds the per-ring maxima (cfl_last_workgroup): one launch
+        // (finalize = 0: the final fold as its own small launch.  Letting the last workgroup of k_cfl_rings do it --
+        // cfl_last_workgroup, one agent-scope release per workgroup -- was measured at 110 instead of 36 + 6 us: on
+        // this GPU a device-scope release writes the XCD's L2 back, 2048 times per launch.)
         if (interior_done)
-            launch_cfl_rings(P, 0, CFL_EDGE_LO, P.nr - CFL_EDGE_HI, CFL_EDGE_HI, 1 + apply_policy, st);
+            launch_cfl_rings(P, 0, CFL_EDGE_LO, P.nr - CFL_EDGE_HI, CFL_EDGE_HI, 0, st);
         else
-            launch_cfl_rings(P, 0, P.nr, 0, 0, 1 + apply_policy, st);
+            launch_cfl_rings(P, 0, P.nr, 0, 0, 0, st);
+        KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
         return;
     }
     KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 0, (const double *)nullptr, 0, P.ring_pstride);

@@ -11,11 +11,12 @@ import collections, csv, glob, json, re, sys
 d = sys.argv[1]
 src = sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "2048x4096"
+eos = sys.argv[4] if len(sys.argv) > 4 else "isothermal"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(d + "/pass*/*/*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"workload": workload, "source": src,
+out = {"workload": workload, "eos": eos, "source": src,
        "note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
                "(profiles/run_pmc.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a "
                "coalesced stream; calibrated on k_velocities in round 1). valu_busy = SQ_ACTIVE_INST_VALU / "
