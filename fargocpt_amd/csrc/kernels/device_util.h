@@ -128,8 +128,29 @@ template <int CTRL> __device__ __forceinline__ double dpp_shift(double x)
     return __hiloint2double(hi, lo);
 #endif
 }
+#ifdef FCPT_LDS_SHIFT
+// Experiment: the neighbour's value through the LDS instead of DPP moves.  A wavefront writes its 64 values to its
+// own row and reads them back one slot to the left / right: two LDS instructions (their own issue port) instead of
+// four vector moves.  No barrier: a wavefront's LDS operations execute in order; lanes 0 / 63 read a padding slot
+// (those lanes are halo).  Blocks of at most 4 wavefronts.
+__device__ __forceinline__ double lds_shift(double x, int delta)
+{
+    __shared__ double s_shift[4][80];
+    typedef __attribute__((address_space(3))) double lds_double;
+    lds_double *row = (lds_double *)&s_shift[(threadIdx.x >> 6) & 3][8 + (threadIdx.x & 63)];
+    __builtin_amdgcn_wave_barrier(); // scheduling fence only: the LDS itself keeps a wavefront's operations in order
+    *row = x;
+    __builtin_amdgcn_wave_barrier();
+    const double v = row[delta];
+    __builtin_amdgcn_wave_barrier();
+    return v;
+}
+__device__ __forceinline__ double lane_prev(double x) { return lds_shift(x, -1); }
+__device__ __forceinline__ double lane_next(double x) { return lds_shift(x, 1); }
+#else
 __device__ __forceinline__ double lane_prev(double x) { return dpp_shift<0x138>(x); }
 __device__ __forceinline__ double lane_next(double x) { return dpp_shift<0x130>(x); }
+#endif
 // Sum over the wavefront in a fixed tree order (deterministic), all in the VALU: DPP row shifts
 // build the 16-lane row sums, row_bcast:15 / row_bcast:31 fold the four rows.  The total is valid
 // in lane 63.  (The ds_bpermute butterfly costs six dependent LDS round trips per call.)

@@ -282,15 +282,15 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     auto potential_of = [&](int r, double sg, double en) {
         const double rmed = P.Rmed[r];
         const double x = rmed * cosj, y = rmed * sinj;
-        const double cs = sqrt(gg1 * en * fast_rcp(sg));
-        const double H = cs * inv_sqrt_gamma * P.g_inv_omk[r];
-        const double smooth = P.thickness_smoothing * H;
+        // (ThicknessSmoothing H)^2 with H = c_s / (sqrt(gamma) Omega_K), c_s^2 = gamma (gamma - 1) e / Sigma: no root needed
+        const double hk = P.thickness_smoothing * inv_sqrt_gamma * P.g_inv_omk[r];
+        const double smooth2 = (gg1 * en * fast_rcp(sg)) * (hk * hk);
         double pot = 0.0;
         for (int k = 0; k < P.nbodies; ++k) {
             const double dx = x - P.bx[k];
             const double dy = y - P.by[k];
             const double dist_2 = dx * dx + dy * dy;
-            const double d2s = dist_2 + smooth * smooth;
+            const double d2s = dist_2 + smooth2;
             const double inv_d = fast_rsqrt(d2s); // 1 / d_smoothed
             double klahr = 1.0;
             const double r_sm = P.brsm[k];
