@@ -238,8 +238,14 @@ void apply_options(fcpt_ctx *c, bool at_create = true)
     const Options &o = c->P.opt;
     c->fused_source = o.fused_source != 0;
     c->march_source = o.march_source != 0;
-    if (c->P.stabilize) // the pseudo-implicit viscosity lives in the per-loop kernels only
-        c->fused_source = c->march_source = false;
+    {
+        // StabilizeViscosity is implemented by the marching kernels and by the per-loop kernels, not by the three
+        // intermediate fused ones: where the march does not run (narrow rings, switched off) fall back to the loops
+        const bool march_runs = c->fused_source && c->march_source && c->P.nphi >= 128 &&
+                                (!c->P.adiabatic || o.march_source_adi != 0);
+        if (c->P.stabilize && !march_runs)
+            c->fused_source = c->march_source = false;
+    }
     const bool adi_march =
         c->P.adiabatic && c->fused_source && c->march_source && c->P.nphi >= 128 && o.march_source_adi != 0;
     c->P.lazy_derived = adi_march ? 1 : 0;

@@ -161,11 +161,17 @@ int launch_source_march(const Dev &P, hipStream_t st)
         const dim3 grid((segs * chunks + 3) / 4), block(256);
         const bool cool = P.cooling_surface != 0 || P.cooling_beta != 0 || P.heating_star != 0;
         const int ring_sums = segs <= P.ring_pstride && P.opt.source_ring_parts != 0;
-#define ADIKP(AV_, POT_)                                                                                      \
-    if (cool)                                                                                                 \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, true, POT_>), grid, block, P, segs, rows, ring_sums); \
-    else                                                                                                      \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, false, POT_>), grid, block, P, segs, rows, ring_sums)
+#define ADIKS(AV_, COOL_, POT_)                                                                                           \
+    if (P.stabilize)                                                                                                      \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, COOL_, POT_, true>), grid, block, P, segs, rows, ring_sums);  \
+    else                                                                                                                  \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, COOL_, POT_, false>), grid, block, P, segs, rows, ring_sums)
+#define ADIKP(AV_, POT_)         \
+    if (cool) {                  \
+        ADIKS(AV_, true, POT_);  \
+    } else {                     \
+        ADIKS(AV_, false, POT_); \
+    }
 #define ADIK(AV_)            \
     if (P.inline_potential) { \
         ADIKP(AV_, true);    \
@@ -181,6 +187,7 @@ int launch_source_march(const Dev &P, hipStream_t st)
         }
 #undef ADIK
 #undef ADIKP
+#undef ADIKS
         return ring_sums ? segs : -segs; // < 0: marched, but no ring sums
     }
     // measured at 2048x4096: 16 / 24 / 32 / 48 / 64 rings -> 0.133 / 0.132 / 0.141 / 0.152 / 0.188 ms
@@ -192,12 +199,19 @@ int launch_source_march(const Dev &P, hipStream_t st)
     const int chunks = (P.nr + 1 + rows - 1) / rows;
     const int waves = segs * chunks;
     const dim3 grid((waves + 3) / 4), block(256);
-    if (P.art_visc == FCPT_ARTVISC_TW)
-        KLAUNCH(KID_SOURCE_MARCH, k_source_march<1>, grid, block, P, segs, rows, ring_sums);
-    else if (P.art_visc == FCPT_ARTVISC_SN)
-        KLAUNCH(KID_SOURCE_MARCH, k_source_march<2>, grid, block, P, segs, rows, ring_sums);
-    else
-        KLAUNCH(KID_SOURCE_MARCH, k_source_march<0>, grid, block, P, segs, rows, ring_sums);
+#define ISOK(AV_)                                                                                     \
+    if (P.stabilize)                                                                                  \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, true>), grid, block, P, segs, rows, ring_sums); \
+    else                                                                                              \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, false>), grid, block, P, segs, rows, ring_sums)
+    if (P.art_visc == FCPT_ARTVISC_TW) {
+        ISOK(1);
+    } else if (P.art_visc == FCPT_ARTVISC_SN) {
+        ISOK(2);
+    } else {
+        ISOK(0);
+    }
+#undef ISOK
     return ring_sums ? segs : -segs; // < 0: marched, but no ring sums
 }
 void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_FUSED, k_visc_fused, P.nr + 1, P); }

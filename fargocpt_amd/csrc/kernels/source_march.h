@@ -21,7 +21,45 @@
 #define MARCH_VALID 59
 #define MARCH_LO 3
 
-template <int AV> // 0: none, 1: TW, 2: SN
+// StabilizeViscosity (viscosity.cpp:256-348): the correction factors c1_phi, c1_r of ring k -- the diagonal of the
+// Jacobian of the viscous acceleration -- from the nu Sigma products the stress stages of the march hold anyway:
+// ns_k / ns_k1 / ns_k_jn = VISCOSITY_SIGMA_RP at the corners (k, j), (k+1, j), (k, j+1); nsg, nsg_jm, nsg_im =
+// nu Sigma of the cells (k, j), (k, j-1), (k-1, j); sg, sg_jm, sg_im the densities.
+struct ViscFactors {
+    double cphi, cr;
+};
+__device__ __forceinline__ ViscFactors visc_factors_row(const Dev &P, int k, double ns_k, double ns_k1, double ns_k_jn,
+                                                        double nsg, double nsg_jm, double nsg_im, double sg, double sg_jm,
+                                                        double sg_im)
+{
+    const double Ra = P.Rinf[k], rs = P.Rsup[k];
+    const double TwoDiffRaSq = 2.0 / (rs * rs - Ra * Ra);
+    const double FourThirdInvRbInvdphiSq = 4.0 / 3.0 / P.Rmed[k] * P.invdphi * P.invdphi;
+    const double a0 = ns_k * P.g_ra3[k] * P.InvDiffRmed[k];
+    const double a1 = ns_k1 * P.g_ra3[k + 1] * P.InvDiffRmed[k + 1];
+    const double cphi_rp = -P.InvRmed[k] * TwoDiffRaSq * (a1 + a0);
+    const double cphi_pp = -FourThirdInvRbInvdphiSq * (nsg + nsg_jm);
+    const double sigma_avg_phi = 0.5 * (sg + sg_jm);
+    ViscFactors f;
+    f.cphi = (cphi_rp + cphi_pp) / (sigma_avg_phi * P.Rmed[k]);
+    const double sigma_avg_r = 0.5 * (sg + sg_im);
+    const double cr_rp = -(ns_k_jn + ns_k) / (P.dphi * P.dphi * Ra);
+    const double cr_pp_1 = 2.0 * nsg * (0.5 * P.InvRmed[k] + 1.0 / 3.0 * Ra * P.InvDiffRsupRb[k]);
+    const double cr_pp_2 = 2.0 * nsg_im * (0.5 * P.InvRmed[k - 1] - 1.0 / 3.0 * Ra * P.InvDiffRsupRb[k - 1]);
+    const double cr_rr_1 = P.Rmed[k] * 2.0 * nsg * (-P.InvDiffRsup[k] + 1.0 / 3.0 * Ra * P.InvDiffRsupRb[k]);
+    const double cr_rr_2 = -1.0 * P.Rmed[k - 1] * 2.0 * nsg_im * (P.InvDiffRsup[k - 1] - 1.0 / 3.0 * Ra * P.InvDiffRsupRb[k - 1]);
+    const double cr_pp = -0.5 * (cr_pp_1 + cr_pp_2);
+    const double cr_rr = P.InvDiffRmed[k] * (cr_rr_1 + cr_rr_2);
+    const double Rmed_mid = 0.5 * (P.Rmed[k] + P.Rmed[k - 1]);
+    f.cr = P.radial_viscosity_factor * (cr_rr + cr_rp + cr_pp) / (sigma_avg_r * Rmed_mid);
+    return f;
+}
+// viscosity.cpp:386-391|413-417: corr = 1 / (max(1 + dt c, 0) - dt c)
+__device__ __forceinline__ double visc_corr_march(double dt, double c) { return 1.0 / (dmax(1.0 + dt * c, 0.0) - dt * c); }
+
+// STAB: StabilizeViscosity 1 | 2 -- the correction factors are formed in stage E and stored (the CFL condition of
+// mode 2 and fcpt_download read the grids), mode 1 also damps the viscous velocity update with them.
+template <int AV, bool STAB> // AV 0: none, 1: TW, 2: SN
 __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums)
 {
     const int lane = threadIdx.x & 63;
@@ -52,6 +90,8 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
     double qr_1 = 0, qr_2 = 0, qp_1 = 0, qp_2 = 0;                          // Q_rr/Q_pp (TW) or q_r/q_phi (SN)
     double vr2_1 = 0, vr2_2 = 0, va2_1 = 0, va2_2 = 0;                      // after artificial viscosity
     double trr_2 = 0, trr_3 = 0, tpp_2 = 0, tpp_3 = 0, trp_1 = 0, trp_2 = 0;
+    double nsrp_1 = 0, nsrp_2 = 0; // STAB: nu Sigma at the corners of rings m-1, m-2 (VISCOSITY_SIGMA_RP)
+    double nu_d_prev = 0;          // STAB: viscosity of ring m-3
 
     // ring k0-3 is the "previous" ring of the first iteration
     {
@@ -174,6 +214,10 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
             const int r = m - 1;
             const double vr2p_1 = PREV(vr2_1);
             trp_1 = 0.0;
+            if (STAB) {
+                nsrp_2 = nsrp_1;
+                nsrp_1 = 0.0;
+            }
             if (r >= 1 && r <= nr - 1) {
                 const double dvazirdr = (va2_1 * R.inv_rmed_r - va2_2 * R.inv_rmed_rm1) * R.idr_r;
                 const double dvrdphi = (vr2_1 - vr2p_1) * P.invdphi;
@@ -181,6 +225,8 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                 const double nu = R.nu_avg_r;
                 const double sigma = 0.25 * (S_1 + S_2 + Sp_1 + Sp_2);
                 trp_1 = nu * sigma * drp;
+                if (STAB)
+                    nsrp_1 = nu * sigma;
             }
         }
         // ---- E: viscous update of ring k = m-2 and store ----------------------------------
@@ -188,19 +234,35 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
             const int k = m - 2;
             const double tpp_p = PREV(tpp_2);
             const double trp_n = NEXT(trp_2);
+            const double nsrp_jn = STAB ? NEXT(nsrp_2) : 0.0; // corner (k, j+1)
             if (k >= k0 && k < k1) {
                 double vr3 = vr2_2, va3 = va2_2;
+                double corr_phi = 1.0, corr_r = 1.0;
+                if (STAB && k >= 1 && k <= nr - 1) {
+                    const ViscFactors f = visc_factors_row(P, k, nsrp_2, nsrp_1, nsrp_jn, R.nu_d * S_2, R.nu_d * Sp_2,
+                                                           nu_d_prev * S_3, S_2, Sp_2, S_3);
+                    if (store_lane) {
+                        P.cfac_phi[IDX(k, j)] = f.cphi;
+                        P.cfac_r[IDX(k, j)] = f.cr;
+                    }
+                    if (P.stabilize == 1) {
+                        corr_phi = visc_corr_march(dt, f.cphi);
+                        corr_r = visc_corr_march(dt, f.cr);
+                    }
+                }
                 if (k >= 1 && k < nr - 1) {
                     const double sigma_avg = 0.5 * (S_2 + Sp_2);
-                    va3 = va2_2 + dt * R.inv_rmed_k * fast_rcp(sigma_avg) *
-                                      (R.two_inv_dra2_k * (R.ra1sq_k * trp_1 - R.ra0sq_k * trp_2) +
-                                       (tpp_2 - tpp_p) * P.invdphi);
+                    const double dVp = dt * R.inv_rmed_k * fast_rcp(sigma_avg) *
+                                       (R.two_inv_dra2_k * (R.ra1sq_k * trp_1 - R.ra0sq_k * trp_2) +
+                                        (tpp_2 - tpp_p) * P.invdphi);
+                    va3 = va2_2 + (STAB ? dVp * corr_phi : dVp);
                 }
                 if (k >= P.one_no_ghost_vr && k < P.maxmo_no_ghost_vr) {
                     const double sigma_avg = 0.5 * (S_2 + S_3);
-                    vr3 = vr2_2 + dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
-                                      ((R.rmed_k * trr_2 - R.rmed_km1 * trr_3) * R.idr_k +
-                                       (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
+                    const double dVr = dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
+                                       ((R.rmed_k * trr_2 - R.rmed_km1 * trr_3) * R.idr_k +
+                                        (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
+                    vr3 = vr2_2 + (STAB ? dVr * corr_r : dVr);
                 }
                 if (store_lane) {
                     P.vrad_b[IDX(k, j)] = vr3;
@@ -214,6 +276,8 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                 }
             }
         }
+        if (STAB)
+            nu_d_prev = R.nu_d;
     }
 #undef NEXT
 #undef PREV
@@ -236,7 +300,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
 // POT: the potential of ring m is evaluated here (CalculateNbodyPotential, Pframeforce.cpp:21-94, with the
 // smoothing length ThicknessSmoothing * H of the cell, Force.cpp:124-159) instead of read from the grid
 // k_potential would have to refresh every step, because H follows the energy.
-template <int AV, bool COOL, bool POT> // AV 0: none, 1: TW, 2: SN
+template <int AV, bool COOL, bool POT, bool STAB> // AV 0: none, 1: TW, 2: SN
 __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs, int rows_per_chunk, int ring_sums)
 {
     const int lane = threadIdx.x & 63;
@@ -275,6 +339,7 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     double qr_1 = 0, qr_2 = 0, qp_1 = 0, qp_2 = 0;                          // Q_rr/Q_pp (TW) or q_r/q_phi (SN)
     double vr2_1 = 0, vr2_2 = 0, va2_1 = 0, va2_2 = 0;                      // after artificial viscosity
     double trr_2 = 0, trr_3 = 0, tpp_2 = 0, tpp_3 = 0, trp_1 = 0, trp_2 = 0;
+    double nsrp_1 = 0, nsrp_2 = 0, nu_3 = 0; // STAB: nu Sigma at the corners of rings m-1, m-2; viscosity of ring m-3
 
     // k_potential in registers: this lane's column (cos phi_j, sin phi_j) against the bodies
     const double cosj = POT ? P.cosphi[j] : 0.0, sinj = POT ? P.sinphi[j] : 0.0;
@@ -329,6 +394,8 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
         F_1 = F_m; Pr_1 = Pr_m; e0_1 = e0_m;
         va0_1 = va0_m; va0n_1 = va0n_m;
         vr1_1 = vr1_m; va1_1 = va1_m;
+        if (STAB)
+            nu_3 = nu_2;
         e2_2 = e2_1; nu_2 = nu_1; nup_2 = nup_1; H_2 = H_1;
         S_m = pS; F_m = pF; va0_m = pVa; e0_m = pE;
         const double vr0_m = pVr;
@@ -454,6 +521,10 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
             const int r = m - 1;
             const double vr2p_1 = PREV(vr2_1);
             trp_1 = 0.0;
+            if (STAB) {
+                nsrp_2 = nsrp_1;
+                nsrp_1 = 0.0;
+            }
             if (r >= 1 && r <= nr - 1) {
                 const double dvazirdr = (va2_1 * R.inv_rmed_r - va2_2 * R.inv_rmed_rm1) * R.idr_r;
                 const double dvrdphi = (vr2_1 - vr2p_1) * P.invdphi;
@@ -461,6 +532,8 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
                 const double nu = 0.25 * (nu_1 + nu_2 + nup_1 + nup_2);
                 const double sigma = 0.25 * (S_1 + S_2 + Sp_1 + Sp_2);
                 trp_1 = nu * sigma * drp;
+                if (STAB)
+                    nsrp_1 = nu * sigma;
             }
         }
         // ---- E: viscous update, viscous heating and SubStep3 of ring k = m-2, store -------
@@ -469,20 +542,36 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
             const double tpp_p = PREV(tpp_2);
             const double trp_n = NEXT(trp_2);
             const double trp_1n = NEXT(trp_1);
+            const double nsrp_jn = STAB ? NEXT(nsrp_2) : 0.0; // corner (k, j+1)
             if (k >= k0 && k < k1) {
                 double vr3 = vr2_2, va3 = va2_2;
                 const bool row_va = k >= 1 && k < nr - 1;
+                double corr_phi = 1.0, corr_r = 1.0;
+                if (STAB && k >= 1 && k <= nr - 1) {
+                    const ViscFactors f = visc_factors_row(P, k, nsrp_2, nsrp_1, nsrp_jn, nu_2 * S_2, nup_2 * Sp_2,
+                                                           nu_3 * S_3, S_2, Sp_2, S_3);
+                    if (store_lane) {
+                        P.cfac_phi[IDX(k, j)] = f.cphi;
+                        P.cfac_r[IDX(k, j)] = f.cr;
+                    }
+                    if (P.stabilize == 1) {
+                        corr_phi = visc_corr_march(dt, f.cphi);
+                        corr_r = visc_corr_march(dt, f.cr);
+                    }
+                }
                 if (row_va) {
                     const double sigma_avg = 0.5 * (S_2 + Sp_2);
-                    va3 = va2_2 + dt * R.inv_rmed_k * fast_rcp(sigma_avg) *
-                                      (R.two_inv_dra2_k * (R.ra1sq_k * trp_1 - R.ra0sq_k * trp_2) +
-                                       (tpp_2 - tpp_p) * P.invdphi);
+                    const double dVp = dt * R.inv_rmed_k * fast_rcp(sigma_avg) *
+                                       (R.two_inv_dra2_k * (R.ra1sq_k * trp_1 - R.ra0sq_k * trp_2) +
+                                        (tpp_2 - tpp_p) * P.invdphi);
+                    va3 = va2_2 + (STAB ? dVp * corr_phi : dVp);
                 }
                 if (k >= P.one_no_ghost_vr && k < P.maxmo_no_ghost_vr) {
                     const double sigma_avg = 0.5 * (S_2 + S_3);
-                    vr3 = vr2_2 + dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
-                                      ((R.rmed_k * trr_2 - R.rmed_km1 * trr_3) * R.idr_k +
-                                       (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
+                    const double dVr = dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
+                                       ((R.rmed_k * trr_2 - R.rmed_km1 * trr_3) * R.idr_k +
+                                        (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
+                    vr3 = vr2_2 + (STAB ? dVr * corr_r : dVr);
                 }
                 double qplus = 0.0, qminus = 0.0, e = e2_2;
                 if (k < nr) {
