@@ -468,6 +468,10 @@ def config_table(lib, args):
     one("4 on one GPU: isothermal 2048x6144", d, setups.jupiter_bodies(d))
     d = setups.shocktube(lib, 4096, 4, "SN")
     one("5: shock tube 4096x4, SN artificial viscosity", d, steps=max(args.steps, 200))
+    d = setups.planet_disk(lib, 2048, 4096)
+    d.stabilize_viscosity = 1
+    one("headline workload with StabilizeViscosity: 1 (pseudo-implicit viscous update in the marching kernel)", d,
+        setups.jupiter_bodies(d))
     return rows
 
 

@@ -2,11 +2,13 @@
 #include "fcpt_comm.h"
 
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "fcpt_internal.h"
 
@@ -38,6 +40,21 @@ void bind_rccl()
     //    RCCL instances, or one bound to another HIP runtime than the kernels of this library, must be avoided)
     // 2. FCPT_RCCL_PATH  3. the ROCm installation this library was built against
     const char *env = getenv("FCPT_RCCL_PATH");
+    {
+        // (PyTorch's copy carries no SONAME: look for it among the loaded objects by path)
+        std::string loaded;
+        dl_iterate_phdr(
+            [](struct dl_phdr_info *info, size_t, void *out) {
+                if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl.so")) {
+                    *static_cast<std::string *>(out) = info->dlpi_name;
+                    return 1;
+                }
+                return 0;
+            },
+            &loaded);
+        if (!loaded.empty())
+            r.handle = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    }
     for (const char *name : {"librccl.so", "librccl.so.1"})
         if (!r.handle)
             r.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
