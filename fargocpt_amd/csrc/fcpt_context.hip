@@ -48,6 +48,8 @@ struct fcpt_ctx {
     bool stepped = false; // fcpt_step ran since the last fcpt_post
     bool cfl_interior = false; // fcpt_cfl_begin evaluated the interior rings of the current state
     bool damp_any = false;     // this slab holds rings of a damping zone
+    double *thermal_grid = nullptr; // storage of Dev::cfl_thermal (the view's pointer is null when the option is off)
+    bool thermal_valid = false;     // ... and it describes the current state (set by a marching-transport step)
     bool damp_foldable = false; // ... and its damping can be folded into the transport (no "mean" target, Euler)
     // fcpt_step_device_begin: the interior chunks of the transport run on `side` while the caller's stream
     // marches the chunks with the neighbours' ghost rings, packs and sends them
@@ -99,6 +101,7 @@ void options_from_environment(Options &o)
     o.transport_fallback = o.transport_split = o.fused_source = o.march_source = o.march_source_adi = 1;
     o.theta_march = o.theta_fused = o.cfl_rings = o.cfl_split = o.source_ring_parts = o.fused_damping = 1;
     o.inline_potential = 1;
+    o.cfl_thermal = 1;
     o.comm_overlap = 0;
     o.comm_loopback = 0;
     o.graph_steps = -1;
@@ -250,6 +253,10 @@ void apply_options(fcpt_ctx *c, bool at_create = true)
         c->P.adiabatic && c->fused_source && c->march_source && c->P.nphi >= 128 && o.march_source_adi != 0;
     c->P.lazy_derived = adi_march ? 1 : 0;
     c->P.inline_potential = (adi_march && !c->P.leapfrog && o.inline_potential != 0) ? 1 : 0;
+    // the transport leaves the cell-local CFL terms only where the CFL kernel that reads them will run (lazy derived
+    // quantities, Euler: the leapfrog's second kick changes e after the transport)
+    c->P.cfl_thermal = (adi_march && !c->P.leapfrog && o.cfl_thermal != 0) ? c->thermal_grid : nullptr;
+    c->thermal_valid = false;
     c->P.damp_in_step = (c->damp_foldable && o.fused_damping != 0) ? 1 : 0;
     c->cfl_interior = false;
     c->potential_valid = false;
@@ -435,6 +442,10 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool spl
     }
     if (!tr.marched)
         launch_clock_advance(P.clk, st);
+    // a marching transport kernel stored the cell-local CFL terms with the new Sigma and e; they stay those of the
+    // final state if nothing but boundary rings and ghost rows changes before the next CFL reduction (the wave
+    // damping folded into that kernel, or no damping zone on this slab)
+    c->thermal_valid = P.cfl_thermal != nullptr && tr.marched > 0 && !frog && (!c->damp_any || P.damp_in_step != 0);
     // the marching transport is out of place: the new state may sit in the scratch twins
     if (tr.sigma != c->P.sigma)
         std::swap(c->P.sigma, c->P.sigA);
@@ -760,6 +771,10 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     if (d->write_massflow) {
         AL(massflow, nv)
     }
+    double *thermal_grid = nullptr; // ideal EOS: the cell-local CFL terms left by the marching transport
+    if (!rc && d->eos == FCPT_EOS_IDEAL)
+        rc = dev_alloc(c, &thermal_grid, ns);
+    c->thermal_grid = thermal_grid;
 #undef AL
     if (!rc && hipHostMalloc((void **)&c->h_clk, sizeof(DevClock)) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -1083,7 +1098,10 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
         c->pressure_valid = false;
         c->potential_valid = false;
         c->stepped = false;
+        c->thermal_valid = false;
     }
+    if (f == FCPT_F_QPLUS || f == FCPT_F_QMINUS)
+        c->thermal_valid = false;
     if (f == FCPT_F_SCALE_HEIGHT)
         c->potential_valid = false;
     c->cfl_interior = false;
@@ -1239,6 +1257,7 @@ int fcpt_init_physics(fcpt_ctx *c)
         return rc;
     c->potential_valid = false;
     c->pressure_valid = true;
+    c->thermal_valid = false;
     HIPCHK(hipGetLastError());
     return FCPT_OK;
 }
@@ -1248,6 +1267,7 @@ namespace {
 void enqueue_cfl(fcpt_ctx *c, int apply_policy)
 {
     join_side(c);
+    c->P.cfl_thermal_on = c->thermal_valid ? 1 : 0;
     launch_cfl(c->P, apply_policy, c->stream, c->cfl_interior);
     c->cfl_interior = false;
 }
@@ -1264,6 +1284,7 @@ int fcpt_recalculate_derived(fcpt_ctx *c)
     c->stepped = false;
     c->cfl_interior = false;
     c->potential_valid = false;
+    c->thermal_valid = false;
     if (c->P.adiabatic && !c->P.lazy_derived) {
         launch_derived(c->P, c->stream);
         c->pressure_valid = true;
@@ -1290,6 +1311,7 @@ int fcpt_cfl_begin(fcpt_ctx *c)
     if (c->P.opt.cfl_split == 0)
         return FCPT_OK;
     ProfScope prof_scope(c);
+    c->P.cfl_thermal_on = c->thermal_valid ? 1 : 0;
     c->cfl_interior = launch_cfl_interior(c->P, c->stream);
     HIPCHK(hipGetLastError());
     return FCPT_OK;
@@ -1445,6 +1467,8 @@ int fcpt_apply_boundary(fcpt_ctx *c, double dt, int32_t final)
     join_side(c);
     ProfScope prof_scope(c);
     launch_clock_set_dt(c->P.clk, dt, c->stream);
+    if (final && c->damp_any)
+        c->thermal_valid = false; // the wave damping changes Sigma and e of the damping zones
     apply_boundary(c, final != 0);
     HIPCHK(hipGetLastError());
     return FCPT_OK;
@@ -1716,6 +1740,7 @@ unsigned launch_flags(const fcpt_ctx *c)
     return (c->potential_valid ? 1u : 0u) | (c->pressure_valid ? 2u : 0u) | (c->stepped ? 4u : 0u) |
            (c->cfl_interior ? 8u : 0u) | (c->kick_energy_b ? 16u : 0u) | (c->fused_source ? 32u : 0u) |
            (c->march_source ? 64u : 0u) | (c->has_mid ? 128u : 0u) | (c->join_pending ? 256u : 0u) |
+           (c->thermal_valid ? 512u : 0u) |
            ((unsigned)c->src_parts << 12);
 }
 bool graph_wanted(const fcpt_ctx *c)
@@ -1768,6 +1793,7 @@ bool capture_graph(fcpt_ctx *c, int cycle)
         c->stepped = f0 & 4u;
         c->cfl_interior = f0 & 8u;
         c->kick_energy_b = f0 & 16u;
+        c->thermal_valid = f0 & 512u;
         c->src_parts = (int)(f0 >> 12);
         drop_graph(c);
         return false;

@@ -137,6 +137,7 @@ struct Options {
     int source_ring_parts;  // 0: the transport's ring mean re-reads v_phi
     int fused_damping;      // 0: the wave damping as separate kernels in the final boundary call
     int inline_potential;   // 0: ideal EOS: k_potential every step instead of the evaluation inside k_source_march_adi
+    int cfl_thermal;        // 0: ideal EOS: the CFL kernel re-reads Sigma, e, Q+, Q- instead of the transport's per-cell sum
     int comm_overlap;       // fcpt_exchange: transfers on the library's communication stream under the interior CFL
     int comm_loopback;      // rehearsal on one GPU: both "neighbours" of the slab are the slab itself
     int graph_steps;        // fcpt_run_steps: replay a captured hipGraph of one step (launch-bound narrow grids)
@@ -144,7 +145,7 @@ struct Options {
 #define FCPT_OPTION_NAMES                                                                                        \
     X(transport_fused) X(transport_rows) X(source_rows) X(theta_rows) X(transport_fallback) X(transport_split)    \
     X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_split)   \
-    X(source_ring_parts) X(fused_damping) X(inline_potential) X(comm_overlap) X(comm_loopback) X(graph_steps)
+    X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(comm_overlap) X(comm_loopback) X(graph_steps)
 
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.
 struct Dev {
@@ -200,6 +201,8 @@ struct Dev {
     int damp_in_step;
     CArrI nshift_c;
     double *cfl_part; // per-block maxima of the CFL reduction
+    double *cfl_thermal; // ideal EOS: invdt1^2 + invdt5^2 + invdt6^2 per cell, left by the marching transport (null: off)
+    int cfl_thermal_on;  // ... and valid for the current state: k_cfl_rings reads it instead of Sigma, e, Q+, Q-
     int *cfl_tickets; // 1 + CFL_TICKET_LANES counters of the "last workgroup folds" scheme (zero between launches)
     // per-ring partial sums of v_phi left by k_source_march for the transport's ring mean
     // (pstride entries per ring, src_ring_nparts of them valid, 0 = not available)

@@ -149,8 +149,11 @@ template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings
                 const int j = 2 * p;
                 const D2 r0 = *(const D2 *)(P.vrad + row + j), r1 = *(const D2 *)(P.vrad + row + nphi + j);
                 const double van1 = P.vazi[row + (j + 2 >= nphi ? 0 : j + 2)]; // v_phi of cell j+2
-                D2 e2 = {0.0, 0.0}, s2 = {1.0, 1.0}, qp = {0.0, 0.0}, qm = {0.0, 0.0};
-                if (ADI) {
+                D2 e2 = {0.0, 0.0}, s2 = {1.0, 1.0}, qp = {0.0, 0.0}, qm = {0.0, 0.0}, th = {0.0, 0.0};
+                const bool thermal = ADI && P.cfl_thermal_on != 0; // invdt1^2 + invdt5^2 + invdt6^2 left by the transport
+                if (thermal) {
+                    th = *(const D2 *)(P.cfl_thermal + row + j);
+                } else if (ADI) {
                     e2 = *(const D2 *)(P.energy + row + j);
                     s2 = *(const D2 *)(P.sigma + row + j);
                     qp = *(const D2 *)(P.qplus + row + j);
@@ -161,7 +164,7 @@ template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings
                     const double vr0 = c ? r0.y : r0.x, vr1 = c ? r1.y : r1.x;
                     const double v = c ? va[n].y : va[n].x, van = c ? van1 : va[n].y;
                     double cs = cs_iso, nu = nu_iso;
-                    if (ADI) { // k_adi_cs_h + k_viscosity in registers
+                    if (ADI && !thermal) { // k_adi_cs_h + k_viscosity in registers
                         const double e = c ? e2.y : e2.x, sg = c ? s2.y : s2.x;
                         cs = sqrt(gg1 * e * fast_rcp(sg));
                         const double H = cs * inv_sqrt_gamma * inv_omk;
@@ -185,12 +188,15 @@ template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings
                     }
                     const double invdt5 = 4.0 * nu * (inv_cell * inv_cell) * lf;
                     double invdt6 = 0.0;
-                    if (ADI) {
+                    if (ADI && !thermal) {
                         const double e = c ? e2.y : e2.x;
                         invdt6 = inv_limit * fabs(((c ? qp.y : qp.x) - (c ? qm.y : qm.x)) * fast_rcp(e)) * lf;
                     }
-                    s = dmax(s, invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 +
-                                    invdt5 * invdt5 + invdt6 * invdt6);
+                    if (thermal)
+                        s = dmax(s, (c ? th.y : th.x) + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4);
+                    else
+                        s = dmax(s, invdt1 * invdt1 + invdt2 * invdt2 + invdt3 * invdt3 + invdt4 * invdt4 +
+                                        invdt5 * invdt5 + invdt6 * invdt6);
                 }
             }
         }

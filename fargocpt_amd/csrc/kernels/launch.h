@@ -161,16 +161,18 @@ int launch_source_march(const Dev &P, hipStream_t st)
         const dim3 grid((segs * chunks + 3) / 4), block(256);
         const bool cool = P.cooling_surface != 0 || P.cooling_beta != 0 || P.heating_star != 0;
         const int ring_sums = segs <= P.ring_pstride && P.opt.source_ring_parts != 0;
-#define ADIKS(AV_, COOL_, POT_)                                                                                           \
-    if (P.stabilize)                                                                                                      \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, COOL_, POT_, true>), grid, block, P, segs, rows, ring_sums);  \
-    else                                                                                                                  \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, COOL_, POT_, false>), grid, block, P, segs, rows, ring_sums)
-#define ADIKP(AV_, POT_)         \
-    if (cool) {                  \
-        ADIKS(AV_, true, POT_);  \
-    } else {                     \
-        ADIKS(AV_, false, POT_); \
+#define ADIKS(AV_, COOL_, POT_)                                                                                               \
+    if (P.stabilize)                                                                                                          \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi_wide<AV_, COOL_, POT_, true>), grid, block, P, segs, rows, ring_sums); \
+    else                                                                                                                      \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi_wide<AV_, COOL_, POT_, false>), grid, block, P, segs, rows, ring_sums)
+#define ADIKP(AV_, POT_)                                                                                    \
+    if (cool) {                                                                                             \
+        ADIKS(AV_, true, POT_);                                                                             \
+    } else if (P.stabilize) {                                                                               \
+        ADIKS(AV_, false, POT_);                                                                            \
+    } else {                                                                                                \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, POT_>), grid, block, P, segs, rows, ring_sums); \
     }
 #define ADIK(AV_)            \
     if (P.inline_potential) { \
@@ -417,22 +419,30 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
             ch = TfChunks{c_lo - lead, 0, lead, 0};
         res.split = part != TRANSPORT_ALL;
         const dim3 grid((ch.count * tiles + 3) / 4), block(256);
-#define TFK(CC, AA, DD)                                                                                             \
+#define TFK2(KK, CC, AA, DD)                                                                                        \
     if (P.limiter == FCPT_LIMITER_MC)                                                                                \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback, ch); \
+        KLAUNCH(KID_TRANSPORT_FUSED, (KK<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback, ch); \
     else                                                                                                             \
-        KLAUNCH(KID_TRANSPORT_FUSED, (k_transport_fused<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, fallback, ch)
-#define TFC(CC)               \
-    if (P.adiabatic) {        \
-        if (W.damp_in_step)   \
-            TFK(CC, true, true);  \
-        else                  \
-            TFK(CC, true, false); \
-    } else {                  \
-        if (W.damp_in_step)   \
-            TFK(CC, false, true); \
-        else                  \
-            TFK(CC, false, false);\
+        KLAUNCH(KID_TRANSPORT_FUSED, (KK<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, fallback, ch)
+#define TFK(CC, AA, DD)                                \
+    if (CC == 1) {                                     \
+        TFK2(k_transport_fused, 1, AA, DD);            \
+    } else {                                           \
+        TFK2(k_transport_fused_wide, 2, AA, DD);       \
+    }
+#define TFC(CC)                    \
+    if (P.adiabatic) {             \
+        if (W.damp_in_step) {      \
+            TFK(CC, true, true)    \
+        } else {                   \
+            TFK(CC, true, false)   \
+        }                          \
+    } else {                       \
+        if (W.damp_in_step) {      \
+            TFK(CC, false, true)   \
+        } else {                   \
+            TFK(CC, false, false)  \
+        }                          \
     }
         if (CF == 2) {
             TFC(2)
@@ -441,6 +451,7 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         }
 #undef TFC
 #undef TFK
+#undef TFK2
         // behind it, the two-kernel form: its blocks return at once unless the fused kernel met
         // |Nshift[i] - Nshift[i-1]| > 1 (a time step beyond the FARGO shear limit)
         if (fallback) {

@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
 // smoothing length ThicknessSmoothing * H of the cell, Force.cpp:124-159) instead of read from the grid
 // k_potential would have to refresh every step, because H follows the energy.
 template <int AV, bool COOL, bool POT, bool STAB> // AV 0: none, 1: TW, 2: SN
-__global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs, int rows_per_chunk, int ring_sums)
+__device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, int rows_per_chunk, int ring_sums)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -328,13 +328,15 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     auto vrow = [nr](int r) { return r < 0 ? 0 : (r > nr ? nr : r); };           // v_r rows
 
     // rolling state (suffix _1.._3 = rings m-1..m-3)
-    double S_m = 0, S_1 = 0, S_2 = 0, S_3 = 0, Sp_m = 0, Sp_1 = 0, Sp_2 = 0; // Sigma and Sigma(j-1)
+    double S_m = 0, S_1 = 0, S_2 = 0, S_3 = 0, Sp_m = 0; // Sigma and Sigma(j-1)
     double F_m = 0, F_1 = 0;                                               // potential
-    double Pr_m = 0, Pr_1 = 0;                                             // pressure
+    // (register diet, 142 -> 128 VGPRs = 4 wavefronts per SIMD: the pressure (gamma - 1) e, Sigma(j-1) and nu(j-1)
+    //  of ring m-2, v_phi(j+1) of ring m-1 and this lane's cos / sin are re-formed where they are used instead of
+    //  carried in the rolling window -- the same values, bit for bit)
     double e0_m = 0, e0_1 = 0;                                             // energy as loaded
     double e2_1 = 0, e2_2 = 0;                                             // after S3 + dissipation + floor
-    double nu_1 = 0, nu_2 = 0, nup_1 = 0, nup_2 = 0, H_1 = 0, H_2 = 0;     // viscosity (and at j-1), scale height
-    double va0_m = 0, va0_1 = 0, va0n_m = 0, va0n_1 = 0;                   // v_phi (input) and (j+1)
+    double nu_1 = 0, nu_2 = 0, nup_1 = 0, H_1 = 0, H_2 = 0;                // viscosity (and at j-1), scale height
+    double va0_m = 0, va0_1 = 0, va0n_m = 0;                               // v_phi (input) and (j+1)
     double vr1_m = 0, vr1_1 = 0, va1_m = 0, va1_1 = 0;                      // after source terms
     double qr_1 = 0, qr_2 = 0, qp_1 = 0, qp_2 = 0;                          // Q_rr/Q_pp (TW) or q_r/q_phi (SN)
     double vr2_1 = 0, vr2_2 = 0, va2_1 = 0, va2_2 = 0;                      // after artificial viscosity
@@ -342,11 +344,10 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     double nsrp_1 = 0, nsrp_2 = 0, nu_3 = 0; // STAB: nu Sigma at the corners of rings m-1, m-2; viscosity of ring m-3
 
     // k_potential in registers: this lane's column (cos phi_j, sin phi_j) against the bodies
-    const double cosj = POT ? P.cosphi[j] : 0.0, sinj = POT ? P.sinphi[j] : 0.0;
     const double gg1 = P.gamma * gm1;
     auto potential_of = [&](int r, double sg, double en) {
         const double rmed = P.Rmed[r];
-        const double x = rmed * cosj, y = rmed * sinj;
+        const double x = rmed * P.cosphi[j], y = rmed * P.sinphi[j]; // (cache hits after the first ring)
         // (ThicknessSmoothing H)^2 with H = c_s / (sqrt(gamma) Omega_K), c_s^2 = gamma (gamma - 1) e / Sigma: no root needed
         const double hk = P.thickness_smoothing * inv_sqrt_gamma * P.g_inv_omk[r];
         const double smooth2 = (gg1 * en * fast_rcp(sg)) * (hk * hk);
@@ -378,7 +379,6 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
         va0_m = P.vazi[IDX(r, j)];
         e0_m = P.energy[IDX(r, j)];
         F_m = POT ? potential_of(r, S_m, e0_m) : P.potential[IDX(r, j)];
-        Pr_m = gm1 * e0_m;
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
     }
@@ -390,13 +390,15 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
         const SrcRow R = crow_load(P.src_tab, m + 2); // every per-ring factor of this iteration, one batch
         // ---- shift the window, take the prefetched ring m, prefetch ring m+1 ------------
-        S_3 = S_2; S_2 = S_1; S_1 = S_m; Sp_2 = Sp_1; Sp_1 = Sp_m;
-        F_1 = F_m; Pr_1 = Pr_m; e0_1 = e0_m;
-        va0_1 = va0_m; va0n_1 = va0n_m;
+        S_3 = S_2; S_2 = S_1; S_1 = S_m;
+        const double Sp_2 = PREV(S_2), Sp_1 = PREV(S_1);
+        F_1 = F_m; e0_1 = e0_m;
+        va0_1 = va0_m;
         vr1_1 = vr1_m; va1_1 = va1_m;
         if (STAB)
             nu_3 = nu_2;
-        e2_2 = e2_1; nu_2 = nu_1; nup_2 = nup_1; H_2 = H_1;
+        e2_2 = e2_1; nu_2 = nu_1; H_2 = H_1;
+        const double nup_2 = PREV(nu_2);
         S_m = pS; F_m = pF; va0_m = pVa; e0_m = pE;
         const double vr0_m = pVr;
         {
@@ -410,9 +412,10 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
         }
         if (POT)
             F_m = potential_of(crow(m), S_m, e0_m);
-        Pr_m = gm1 * e0_m;
+        const double Pr_m = gm1 * e0_m, Pr_1 = gm1 * e0_1;
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
+        const double va0n_1 = NEXT(va0_1);
         const double Fp_m = PREV(F_m);
         const double Prp_m = PREV(Pr_m);
 
@@ -629,4 +632,19 @@ __global__ void __launch_bounds__(256) k_source_march_adi(const Dev P, int segs,
     }
 #undef NEXT
 #undef PREV
+}
+
+// The kernels proper.  Without the cooling terms the body fits 128 VGPRs when the register allocator is told to aim
+// for 4 wavefronts per SIMD (127 VGPRs, no scratch; left alone it settles at 134 = 3 wavefronts); the instantiations
+// with the opacity laws (220+ VGPRs) and with StabilizeViscosity keep their natural allocation.
+template <int AV, bool POT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_source_march_adi(const Dev P, int segs, int rows_per_chunk, int ring_sums)
+{
+    source_march_adi_body<AV, false, POT, false>(P, segs, rows_per_chunk, ring_sums);
+}
+template <int AV, bool COOL, bool POT, bool STAB>
+__global__ void __launch_bounds__(256) k_source_march_adi_wide(const Dev P, int segs, int rows_per_chunk, int ring_sums)
+{
+    source_march_adi_body<AV, COOL, POT, STAB>(P, segs, rows_per_chunk, ring_sums);
 }

@@ -21,6 +21,35 @@ __device__ __forceinline__ double limiter(int type, double a, double b)
     return ab > 0.0 ? 2.0 * ab * fast_rcp1(a + b) : 0.0;
 }
 
+// The cell-local part of the ideal-EOS CFL sum (cfl.cpp:243-247,319-328): invdt1^2 + invdt5^2 + invdt6^2 -- sound
+// speed, viscosity and |Q+ - Q-| / e -- depends on Sigma, e, Q+ and Q- of the cell alone.  The marching transport
+// kernels hold the cell's final Sigma and e when they store them, so they leave that sum in one grid (cfl_thermal)
+// and the next k_cfl_rings reads it instead of Sigma, e, Q+ and Q- (3 grids instead of 6).  c_s^2 = gamma (gamma-1)
+// e / Sigma and nu = alpha H c_s = alpha c_s^2 / (sqrt(gamma) Omega_K) need no root.
+struct ThermalRing {
+    double inv_cell2, nu_fac, lf, inv_limit;
+};
+__device__ __forceinline__ ThermalRing thermal_ring(const Dev &P, int i)
+{
+    ThermalRing t;
+    const double inv_dxr = P.InvDiffRsup[i], inv_dxa = P.InvRmed[i] * P.invdphi;
+    const double inv_cell = dmax(inv_dxr, inv_dxa);
+    t.inv_cell2 = inv_cell * inv_cell;
+    t.nu_fac = P.alpha * (1.0 / sqrt(P.gamma)) * P.g_inv_omk[i];
+    t.lf = P.leapfrog ? 0.6 : 1.0;
+    t.inv_limit = 1.0 / P.heating_cooling_cfl_limit;
+    return t;
+}
+__device__ __forceinline__ double cfl_thermal_term(const Dev &P, const ThermalRing &t, double sg, double e, double qp, double qm)
+{
+    const double re = fast_rcp(e);
+    const double cs2 = P.gamma * (P.gamma - 1.0) * e * fast_rcp(sg);
+    const double nu = P.alpha_viscosity ? t.nu_fac * cs2 : P.nu_const;
+    const double invdt5 = 4.0 * nu * t.inv_cell2 * t.lf;
+    const double invdt6 = t.inv_limit * fabs((qp - qm) * re) * t.lf;
+    return cs2 * t.inv_cell2 + invdt5 * invdt5 + invdt6 * invdt6;
+}
+
 // Upwind "star" state at radial interface k (between rings k-1 and k),
 // compute_star_radial (TransportEuler.cpp:349-406).  wm2..wp1 = Q at rings k-2..k+1.
 // Per-interface geometry of compute_star_radial, loaded once with the (wavefront-uniform)
@@ -698,6 +727,15 @@ __device__ __forceinline__ void transport_theta_march_block(const Dev &P, const 
                         e = damp_value(P, e, ten, fs, ts, dt, P.energy0, g, 0.0);
                 }
                 o_vr[c] = vr, o_va[c] = va, o_s[c] = sf, o_e[c] = e;
+            }
+            if (ADI && P.cfl_thermal) {
+                const ThermalRing tr = thermal_ring(P, i);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (valid[c]) {
+                        const int g = row + jout[c];
+                        P.cfl_thermal[g] = cfl_thermal_term(P, tr, o_s[c], o_e[c], P.qplus[g], P.qminus[g]);
+                    }
             }
             if (pair_out) { // both cells of the lane are final and adjacent in memory
                 if (valid[0]) {

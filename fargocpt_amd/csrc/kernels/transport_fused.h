@@ -44,13 +44,18 @@ __device__ __forceinline__ double damp_apply(double X, int type, double ef, cons
 }
 
 template <int C, bool ADI, bool DAMP, int LIM>
-__global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int has_fallback,
-                                                         const TfChunks ch)
+__device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W, int tiles, int rows, int has_fallback,
+                                                     const TfChunks &ch)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     constexpr int LO = TfHalo<C>::lo, HI = TfHalo<C>::hi;
     constexpr int NQ = ADI ? 6 : 5; // s, rmp, rmm, lp, lm(, e)
     constexpr int lim = LIM;
+    // Register diet of the ideal-EOS instantiation (156 -> 128 VGPRs = 4 instead of 3 wavefronts per SIMD): the raw
+    // energy, the raw v_phi and the slope differences of the previous ring are re-derived from the specific
+    // quantities of the rolling window instead of being carried along (ulp-level differences: e = (e / Sigma) Sigma,
+    // v_phi = ((v_phi + r Omega) r) / r - r Omega)
+    constexpr bool DIET = ADI;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chunk_l = wave / tiles; // chunk within this launch
@@ -105,18 +110,23 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
 
     // rolling window: index 0 = ring m (newest), 1 = m-1, 2 = m-2
     double w[3][NQ][C];  // specific quantities: Sigma, v_r(ring+1), v_r(ring), (v_phi(j+1) + r Omega) r, (v_phi + r Omega) r(, e / Sigma)
-    double er[3][C];     // the energy itself
-    double vp[3][C];     // v_phi as loaded
-    double d1[NQ][C];    // (w(m-1) - w(m-2)) InvDiffRmed[m-1]
+    double er[DIET ? 1 : 3][C];     // the energy itself
+    double vp[DIET ? 1 : 3][C];     // v_phi as loaded
+    double d1[DIET ? 1 : NQ][C];    // (w(m-1) - w(m-2)) InvDiffRmed[m-1]
+    double idr_prev = 0.0;          // DIET: InvDiffRmed[m-1], to re-form d1
     double hs1[NQ][C];   // limited half slope of ring m-2
     double F1[NQ][C];    // flux through interface m-2
     double rmp_prev[C], S_prev[C]; // transported rm+ and Sigma of the previous ring
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            w[0][q][c] = w[1][q][c] = w[2][q][c] = d1[q][c] = hs1[q][c] = F1[q][c] = 0.0;
-        er[0][c] = er[1][c] = er[2][c] = vp[0][c] = vp[1][c] = vp[2][c] = 0.0;
+        for (int q = 0; q < NQ; ++q) {
+            w[0][q][c] = w[1][q][c] = w[2][q][c] = hs1[q][c] = F1[q][c] = 0.0;
+            if (!DIET)
+                d1[q][c] = 0.0;
+        }
+        if (!DIET)
+            er[0][c] = er[1][c] = er[2][c] = vp[0][c] = vp[1][c] = vp[2][c] = 0.0;
         rmp_prev[c] = S_prev[c] = 0.0;
     }
     // raw loads of one ring: Sigma(k), v_phi(k)(, e(k)) and v_r(k+1); zeros outside the grid
@@ -174,9 +184,11 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
             w[0][4][c] = in_k ? (o.va[c] + romega) * r : 0.0;         // L- / Sigma
             if (ADI) {
                 w[0][NQ - 1][c] = in_k ? o.en[c] * fast_rcp(o.sg[c]) : 0.0;
-                er[0][c] = o.en[c];
+                if (!DIET)
+                    er[0][c] = o.en[c];
             }
-            vp[0][c] = o.va[c];
+            if (!DIET)
+                vp[0][c] = o.va[c];
             vr_last[c] = o.vr[c];
         }
     };
@@ -226,7 +238,8 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const double d0 = (w[0][q][c] - w[1][q][c]) * idr_m;
-                    const double hs0 = lim_ok ? half_limiter(lim, d0, d1[q][c]) : 0.0; // ring m-1
+                    const double dprev = DIET ? (w[1][q][c] - w[2][q][c]) * idr_prev : d1[q][c];
+                    const double hs0 = lim_ok ? half_limiter(lim, d0, dprev) : 0.0; // ring m-1
                     const double st = (up[c] ? w[2][q][c] : w[1][q][c]) + dist[c] * (up[c] ? hs1[q][c] : hs0);
                     if (q == 0) {
                         Fc[c] = open ? g * st * w[1][2][c] : 0.0; // mass flux g rho* v
@@ -234,7 +247,8 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                     } else {
                         F0[q][c] = st * Fc[c];
                     }
-                    d1[q][c] = d0;
+                    if (!DIET)
+                        d1[q][c] = d0;
                     hs1[q][c] = hs0;
                 }
             }
@@ -259,8 +273,8 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     Q[q][c] = s0 * w[2][q + 1][c] + (F1[q + 1][c] - F0[q + 1][c]) * invsurf;
-                E[c] = ADI ? er[2][c] + (F1[NQ - 1][c] - F0[NQ - 1][c]) * invsurf : 0.0;
-                V[c] = vadd + (vp[2][c] - mean);
+                E[c] = ADI ? (DIET ? s0 * w[2][NQ - 1][c] : er[2][c]) + (F1[NQ - 1][c] - F0[NQ - 1][c]) * invsurf : 0.0;
+                V[c] = vadd + ((DIET ? w[2][4][c] * ti.invr - ti.r_omega : vp[2][c]) - mean);
             }
             const double dxtheta = ti.dxtheta;
             const double invdx = ti.inv_dxtheta;
@@ -345,13 +359,24 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
                 w[1][q][c] = w[0][q][c];
                 F1[q][c] = F0[q][c];
             }
-            er[2][c] = er[1][c], er[1][c] = er[0][c];
-            vp[2][c] = vp[1][c], vp[1][c] = vp[0][c];
+            if (!DIET) {
+                er[2][c] = er[1][c], er[1][c] = er[0][c];
+                vp[2][c] = vp[1][c], vp[1][c] = vp[0][c];
+            }
         }
+        if (DIET)
+            idr_prev = rk.idr_up;
         if (m < r1 + 1) {
             convert(m + 1, nxt);
             if (m < r1)
                 fetch(m + 2, nxt);
+        }
+        if (ADI && out_on && W.cfl_thermal) { // the cell-local CFL terms of the new state (cfl_thermal_term)
+            const ThermalRing tr = thermal_ring(W, i);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (valid[c])
+                    W.cfl_thermal[out_g[c]] = cfl_thermal_term(W, tr, o_s[c], o_e[c], W.qplus[out_g[c]], W.qminus[out_g[c]]);
         }
         if (out_on) {
             if (out_pair) {
@@ -387,4 +412,21 @@ __global__ void __launch_bounds__(256) k_transport_fused(const Dev P, const Dev 
             }
         }
     }
+}
+
+// The kernels proper.  One cell per lane: the register allocator is told to aim for 4 wavefronts per SIMD (<= 128
+// VGPRs, no scratch in any instantiation; left alone the ideal-EOS one with the CFL terms settles at 136 = 3
+// wavefronts).  Two cells per lane (the tuning variant transport_fused = 2, 230-290 VGPRs) keeps its natural allocation.
+template <int C, bool ADI, bool DAMP, int LIM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int has_fallback, const TfChunks ch)
+{
+    static_assert(C == 1, "the 4-wavefront kernel is the one-cell-per-lane form");
+    transport_fused_body<C, ADI, DAMP, LIM>(P, W, tiles, rows, has_fallback, ch);
+}
+template <int C, bool ADI, bool DAMP, int LIM>
+__global__ void __launch_bounds__(256) k_transport_fused_wide(const Dev P, const Dev W, int tiles, int rows, int has_fallback,
+                                                              const TfChunks ch)
+{
+    transport_fused_body<C, ADI, DAMP, LIM>(P, W, tiles, rows, has_fallback, ch);
 }
