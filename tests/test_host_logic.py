@@ -159,20 +159,25 @@ def test_hot_kernel_occupancy_budget():
         m = re.search(r"remark:\s+([A-Za-z /\[\]]+): (\d+)", line)
         if m and name:
             usage[name][m.group(1).strip()] = int(m.group(2))
-    budget = {  # mangled-name fragment -> minimum waves per SIMD
-        "k_transport_fusedILi1ELb0ELb1ELi0E": 4,   # isothermal, damping folded in, van Leer: the bench kernel
-        "k_transport_fusedILi1ELb1ELb1ELi0E": 3,   # ideal EOS
-        "14k_source_marchILi1E": 6,                # isothermal source step, TW artificial viscosity
-        "k_source_march_adiILi1ELb0E": 3,          # ideal EOS, no cooling terms compiled in
-        "k_cfl_ringsILb0ELi8E": 6,                 # Nphi <= 4096
-        "k_cfl_ringsILb0ELi16E": 4,                # rings of up to 8192 cells
+    budget = {  # mangled-name fragment -> (minimum waves per SIMD, scratch bytes per lane allowed)
+        "17k_transport_fusedILi1ELb0ELb1ELi0E": (4, 0),   # isothermal, damping folded in, van Leer: the bench kernel
+        # ideal EOS: 4 waves since round 2 (register diet + waves_per_eu); with the cell-local CFL terms stored by the
+        # kernel the allocator parks five dwords in scratch (measured: still faster than 3 waves without them)
+        "17k_transport_fusedILi1ELb1ELb1ELi0E": (4, 32),
+        "14k_source_marchILi1ELb0E": (6, 0),              # isothermal source step, TW artificial viscosity
+        "14k_source_marchILi1ELb1E": (4, 0),              # ... with StabilizeViscosity
+        "18k_source_march_adiILi1ELb1E": (4, 0),          # ideal EOS, potential in the kernel, no cooling terms
+        "k_cfl_ringsILb0ELi8E": (6, 0),                   # Nphi <= 4096
+        "k_cfl_ringsILb0ELi16E": (4, 0),                  # rings of up to 8192 cells
     }
-    for frag, waves in budget.items():
+    for frag, (waves, scratch) in budget.items():
         hits = [k for k in usage if frag in k]
         assert hits, frag
         u = usage[hits[0]]
         assert u["Occupancy [waves/SIMD]"] >= waves, (frag, u)
-        assert u["VGPRs Spill"] == 0 and u["ScratchSize [bytes/lane]"] == 0, (frag, u)
+        assert u["ScratchSize [bytes/lane]"] <= scratch, (frag, u)
+        if scratch == 0:
+            assert u["VGPRs Spill"] == 0, (frag, u)
 
 
 def test_nan_radii_of_a_coarse_exponential_grid_are_refused(product, oracle):
