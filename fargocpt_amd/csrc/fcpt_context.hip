@@ -40,6 +40,8 @@ struct fcpt_ctx {
     bool fused_source = true;
     int src_parts = 0; // segments of ring sums left by the last k_source_march
     bool kick_energy_b = false;
+    bool kick_bc_folded = false; // the last kick applied the boundary conditions that follow it
+    bool ghosts_unknown = true;  // a state grid was uploaded since the last boundary call
     // the dt of the next step is the CFL policy's (set by calculate_timestep*, consumed by the step):
     // with CFL <= 0.8 that keeps it inside the FARGO shear limit
     bool policy_dt_dev = false;
@@ -102,6 +104,7 @@ void options_from_environment(Options &o)
     o.theta_march = o.theta_fused = o.cfl_rings = o.cfl_split = o.source_ring_parts = o.fused_damping = 1;
     o.inline_potential = 1;
     o.cfl_thermal = 1;
+    o.bc_fold = 1;
     o.comm_overlap = 0;
     o.comm_loopback = 0;
     o.graph_steps = -1;
@@ -328,12 +331,14 @@ void ensure_pressure(fcpt_ctx *c)
 
 // one gas "kick" (source terms, artificial viscosity, viscosity, SubStep3) with the step length
 // currently in the device clock.  Returns true if the result is in (vrad_b, vazi_b).
-bool enqueue_kick(fcpt_ctx *c)
+bool enqueue_kick(fcpt_ctx *c, bool fold_bc = false)
 {
     const Dev &P = c->P;
     hipStream_t st = c->stream;
+    c->kick_bc_folded = false;
     if (c->fused_source) {
-        const int segs = c->march_source ? launch_source_march(P, st) : 0; // one pass: (v[, e]) -> (v_b[, e_b])
+        // one pass: (v[, e]) -> (v_b[, e_b]); fold_bc: and the boundary call that follows the first kick of a step
+        const int segs = c->march_source ? launch_source_march(P, st, fold_bc, &c->kick_bc_folded) : 0;
         c->src_parts = segs > 0 ? segs : 0;
         c->kick_energy_b = segs != 0 && P.adiabatic;
         if (!segs) {
@@ -413,7 +418,11 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool spl
     else if (!dt_dev)
         launch_clock_set_dt(P.clk, dt, st);
     enqueue_potential(c, false);
-    const bool in_b = enqueue_kick(c);
+    // (after an upload of a state grid the ghost rings may not satisfy the boundary conditions yet: the folded form
+    //  rewrites Sigma's ghost ring while neighbouring wavefronts may still read it -- harmless only when the values
+    //  are the ones already there, so that one step takes the separate launch)
+    const bool in_b = enqueue_kick(c, !c->ghosts_unknown);
+    c->ghosts_unknown = false;
     Dev Q = P; // view with the post-kick velocities
     if (in_b) {
         Q.vrad = P.vrad_b;
@@ -424,7 +433,9 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool spl
     c->kick_energy_b = false;
     Q.src_ring_nparts = in_b ? c->src_parts : 0; // ring sums of v_phi left by k_source_march
     c->src_parts = 0;
-    apply_boundary_view(c, Q, false);
+    if (!c->kick_bc_folded) // (else the source march applied it on its edge chunks)
+        apply_boundary_view(c, Q, false);
+    c->kick_bc_folded = false;
     if (frog)
         launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step (saved in cfl_dt)
     launch_massflow(Q, st); // WriteMassFlow: what this Transport() carries through the interfaces
@@ -1099,6 +1110,7 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
         c->potential_valid = false;
         c->stepped = false;
         c->thermal_valid = false;
+        c->ghosts_unknown = true;
     }
     if (f == FCPT_F_QPLUS || f == FCPT_F_QMINUS)
         c->thermal_valid = false;

@@ -138,6 +138,7 @@ struct Options {
     int fused_damping;      // 0: the wave damping as separate kernels in the final boundary call
     int inline_potential;   // 0: ideal EOS: k_potential every step instead of the evaluation inside k_source_march_adi
     int cfl_thermal;        // 0: ideal EOS: the CFL kernel re-reads Sigma, e, Q+, Q- instead of the transport's per-cell sum
+    int bc_fold;            // 0: the pre-transport boundary call as its own launch instead of inside the source march
     int comm_overlap;       // fcpt_exchange: transfers on the library's communication stream under the interior CFL
     int comm_loopback;      // rehearsal on one GPU: both "neighbours" of the slab are the slab itself
     int graph_steps;        // fcpt_run_steps: replay a captured hipGraph of one step (launch-bound narrow grids)
@@ -145,7 +146,7 @@ struct Options {
 #define FCPT_OPTION_NAMES                                                                                        \
     X(transport_fused) X(transport_rows) X(source_rows) X(theta_rows) X(transport_fallback) X(transport_split)    \
     X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_split)   \
-    X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(comm_overlap) X(comm_loopback) X(graph_steps)
+    X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(comm_overlap) X(comm_loopback) X(graph_steps)
 
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.
 struct Dev {

@@ -63,7 +63,7 @@ void launch_substep3_cooling_only(const Dev &P, hipStream_t st);
 void launch_disk_on_body(const Dev &P, double x, double y, double r_object, double smoothing_fixed, double r_sm, double *out,
                          hipStream_t st);
 void launch_source_fused(const Dev &P, hipStream_t st);
-int launch_source_march(const Dev &P, hipStream_t st);
+int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc = false, bool *bc_folded = nullptr);
 void launch_viscous_fused(const Dev &P, hipStream_t st);
 void launch_substep3_after_fused(const Dev &P, hipStream_t st);
 void launch_derived(const Dev &P, hipStream_t st);

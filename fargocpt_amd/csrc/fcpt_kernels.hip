@@ -17,8 +17,8 @@ namespace fcpt {
 #include "kernels/device_util.h"
 #include "kernels/source_loops.h"
 #include "kernels/source_fused.h"
-#include "kernels/source_march.h"
 #include "kernels/boundary.h"
+#include "kernels/source_march.h"
 #include "kernels/transport.h"
 #include "kernels/transport_fused.h"
 #include "kernels/cfl.h"

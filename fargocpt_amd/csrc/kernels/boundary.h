@@ -106,22 +106,25 @@ __device__ __forceinline__ BcScalar bc_scalar_load(const Dev &P, const double *x
     }
     return r;
 }
-__global__ void k_boundary(const Dev P)
+// One column of the ghost rings; `sides`: bit 0 = inner edge, bit 1 = outer edge.  Also called by the marching source
+// kernels for the columns of their edge chunks (the pre-transport boundary call folded into the kick).
+__device__ __forceinline__ void boundary_column(const Dev &P, int j, int sides)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.nphi)
-        return;
     const int Irad = P.nr - 1;
     const int Iv = P.nr; // max_radial of the vector grid
     // ---- loads ---------------------------------------------------------------------------
-    BcScalar sg[2], en[2];
+    BcScalar sg[2] = {{false, 0.0}, {false, 0.0}}, en[2] = {{false, 0.0}, {false, 0.0}};
     for (int outer = 0; outer < 2; ++outer) {
+        if (!((sides >> outer) & 1))
+            continue;
         sg[outer] = bc_scalar_load(P, P.sigma, P.sigma0, P.bc_sigma[outer], outer, j);
         en[outer] = bc_scalar_load(P, P.energy, P.energy0, P.bc_energy[outer], outer, j);
     }
     bool vr_on[2] = {false, false}, va_on[2] = {false, false};
     double vr_g0[2] = {0.0, 0.0}, vr_g1[2] = {0.0, 0.0}, va_g[2] = {0.0, 0.0};
     for (int outer = 0; outer < 2; ++outer) {
+        if (!((sides >> outer) & 1))
+            continue;
         const int type = P.bc_vrad[outer];
         const int g0 = outer ? Iv : 0, g1 = outer ? Iv - 1 : 1, a = outer ? Iv - 2 : 2;
         if (type == FCPT_BC_REFLECTING) { // no rank guard in the reference (reflecting.cpp:15-40)
@@ -160,7 +163,7 @@ __global__ void k_boundary(const Dev P)
     }
     for (int outer = 0; outer < 2; ++outer) {
         const int type = P.bc_vaz[outer];
-        if ((!outer && !P.is_first) || (outer && !P.is_last))
+        if (!((sides >> outer) & 1) || (!outer && !P.is_first) || (outer && !P.is_last))
             continue;
         const int row = outer ? Irad : 0, act = outer ? Irad - 1 : 1;
         const double r = P.Rmed[row];
@@ -199,6 +202,13 @@ __global__ void k_boundary(const Dev P)
         if (va_on[outer])
             P.vazi[IDX(row, j)] = va_g[outer];
     }
+}
+__global__ void k_boundary(const Dev P)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.nphi)
+        return;
+    boundary_column(P, j, 3);
 }
 
 // boundary_conditions/damping.cpp:311-427 (reference), :429-557 (zero), :559-700 (mean):

@@ -147,11 +147,27 @@ static int transport_rows(const Dev &P)
     const int tstride = 64 * CF - (TfHalo<1>::lo + TfHalo<1>::hi);
     return march_rows(P.nr, (P.nphi + tstride - 1) / tstride, TF_ROWS, 5);
 }
-// whole source step in one marching pass (isothermal, Nphi >= 128); returns false if not applicable
-int launch_source_march(const Dev &P, hipStream_t st)
+// whole source step in one marching pass (Nphi >= 128); returns 0 if not applicable, else +-segments (> 0: ring sums
+// of v_phi were left for the transport).  fold_bc: the caller's next call is apply_boundary_condition(final = false) on
+// the kick's result -- *bc_folded reports whether the kernel applied it itself (boundary_column on its edge chunks)
+int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_folded)
 {
+    if (bc_folded)
+        *bc_folded = false;
     if (P.nphi < 128)
         return 0;
+    int bc_fold = 0;
+    {
+        // the boundary conditions read rows 1, 2 and nr-2 .. nr of the kick's result: the wavefront that applies them
+        // must have stored those rows itself
+        const int rows = source_rows(P), chunks = (P.nr + 1 + rows - 1) / rows;
+        const int last_rows = (P.nr + 1) - (chunks - 1) * rows;
+        if (fold_bc && P.opt.bc_fold != 0 && rows >= 3 && last_rows >= 3 && P.nr >= 6 && (!P.adiabatic || P.opt.march_source_adi != 0)) {
+            bc_fold = 1;
+            if (bc_folded)
+                *bc_folded = true;
+        }
+    }
     if (P.adiabatic) {
         if (P.opt.march_source_adi == 0)
             return 0;
@@ -163,16 +179,16 @@ int launch_source_march(const Dev &P, hipStream_t st)
         const int ring_sums = segs <= P.ring_pstride && P.opt.source_ring_parts != 0;
 #define ADIKS(AV_, COOL_, POT_)                                                                                               \
     if (P.stabilize)                                                                                                          \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi_wide<AV_, COOL_, POT_, true>), grid, block, P, segs, rows, ring_sums); \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi_wide<AV_, COOL_, POT_, true>), grid, block, P, segs, rows, ring_sums, bc_fold); \
     else                                                                                                                      \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi_wide<AV_, COOL_, POT_, false>), grid, block, P, segs, rows, ring_sums)
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi_wide<AV_, COOL_, POT_, false>), grid, block, P, segs, rows, ring_sums, bc_fold)
 #define ADIKP(AV_, POT_)                                                                                    \
     if (cool) {                                                                                             \
         ADIKS(AV_, true, POT_);                                                                             \
     } else if (P.stabilize) {                                                                               \
         ADIKS(AV_, false, POT_);                                                                            \
     } else {                                                                                                \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, POT_>), grid, block, P, segs, rows, ring_sums); \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, POT_>), grid, block, P, segs, rows, ring_sums, bc_fold); \
     }
 #define ADIK(AV_)            \
     if (P.inline_potential) { \
@@ -203,9 +219,9 @@ int launch_source_march(const Dev &P, hipStream_t st)
     const dim3 grid((waves + 3) / 4), block(256);
 #define ISOK(AV_)                                                                                     \
     if (P.stabilize)                                                                                  \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, true>), grid, block, P, segs, rows, ring_sums); \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, true>), grid, block, P, segs, rows, ring_sums, bc_fold); \
     else                                                                                              \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, false>), grid, block, P, segs, rows, ring_sums)
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, false>), grid, block, P, segs, rows, ring_sums, bc_fold)
     if (P.art_visc == FCPT_ARTVISC_TW) {
         ISOK(1);
     } else if (P.art_visc == FCPT_ARTVISC_SN) {

@@ -60,7 +60,7 @@ __device__ __forceinline__ double visc_corr_march(double dt, double c) { return 
 // STAB: StabilizeViscosity 1 | 2 -- the correction factors are formed in stage E and stored (the CFL condition of
 // mode 2 and fcpt_download read the grids), mode 1 also damps the viscous velocity update with them.
 template <int AV, bool STAB> // AV 0: none, 1: TW, 2: SN
-__global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums)
+__global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -279,6 +279,18 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
         if (STAB)
             nu_d_prev = R.nu_d;
     }
+    // bc_fold: apply_boundary_condition(final = false) of step_Euler (simulation.cpp:208) on this wavefront's columns of
+    // the post-kick view, right behind its own stores of the rings the conditions read (rows 1, 2 / nr-2 .. nr: the
+    // same lane wrote them; the launcher folds only if the last chunk holds at least three rows)
+    if (bc_fold && store_lane) {
+        const int sides = (k0 == 0 ? 1 : 0) | (k1 == nr + 1 ? 2 : 0);
+        if (sides) {
+            Dev Q = P;
+            Q.vrad = P.vrad_b;
+            Q.vazi = P.vazi_b;
+            boundary_column(Q, j, sides);
+        }
+    }
 #undef NEXT
 #undef PREV
 }
@@ -301,7 +313,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
 // smoothing length ThicknessSmoothing * H of the cell, Force.cpp:124-159) instead of read from the grid
 // k_potential would have to refresh every step, because H follows the energy.
 template <int AV, bool COOL, bool POT, bool STAB> // AV 0: none, 1: TW, 2: SN
-__device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, int rows_per_chunk, int ring_sums)
+__device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -630,6 +642,16 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
             }
         }
     }
+    if (bc_fold && store_lane) { // the pre-transport boundary call on this wavefront's edge columns (see k_source_march)
+        const int sides = (k0 == 0 ? 1 : 0) | (k1 == nr + 1 ? 2 : 0);
+        if (sides) {
+            Dev Q = P;
+            Q.vrad = P.vrad_b;
+            Q.vazi = P.vazi_b;
+            Q.energy = P.energy_b;
+            boundary_column(Q, j, sides);
+        }
+    }
 #undef NEXT
 #undef PREV
 }
@@ -639,12 +661,12 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
 // with the opacity laws (220+ VGPRs) and with StabilizeViscosity keep their natural allocation.
 template <int AV, bool POT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_source_march_adi(const Dev P, int segs, int rows_per_chunk, int ring_sums)
+k_source_march_adi(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 {
-    source_march_adi_body<AV, false, POT, false>(P, segs, rows_per_chunk, ring_sums);
+    source_march_adi_body<AV, false, POT, false>(P, segs, rows_per_chunk, ring_sums, bc_fold);
 }
 template <int AV, bool COOL, bool POT, bool STAB>
-__global__ void __launch_bounds__(256) k_source_march_adi_wide(const Dev P, int segs, int rows_per_chunk, int ring_sums)
+__global__ void __launch_bounds__(256) k_source_march_adi_wide(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 {
-    source_march_adi_body<AV, COOL, POT, STAB>(P, segs, rows_per_chunk, ring_sums);
+    source_march_adi_body<AV, COOL, POT, STAB>(P, segs, rows_per_chunk, ring_sums, bc_fold);
 }
