@@ -32,7 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NR_PER_GPU, NPHI = 2048, 4096
-PARITY_STEPS = 40  # steps of the bench workload that the oracle repeats on the CPU (~10 s on 16 host threads)
+# steps of the bench workload that the oracle repeats on the CPU (120: 20-25 s on 16 host threads; on the GPU ~47 ms
+# queued ahead of the warm-up -- the clocks of a GPU that starts cold settle over ~50 ms, see ms_per_step_blocks)
+PARITY_STEPS = int(os.environ.get("FCPT_BENCH_PARITY_STEPS", "120"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # FP64 vector issue: 256 CUs x 4 SIMDs, one wave instruction per 4 cycles per SIMD for FP64 FMA/MUL/ADD
 # (78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz), MI355X_MICROARCH.md
@@ -235,7 +237,7 @@ def main():
     # ---- parity leg, device half: the same workload on a second context, PARITY_STEPS steps from the same initial
     # state; the oracle repeats them on the host cores after the timed region and the two end states are compared
     # (cpu_baseline.parity_max_rel).  Queued here, ahead of the warm-up: the timed region then starts on a GPU
-    # that has been busy for ~20 ms instead of ~2 ms (see ms_per_step_blocks for what that is worth).
+    # that has been busy for ~50 ms instead of ~2 ms (see ms_per_step_blocks for what that is worth).
     parity_ctx = None
     if world == 1 and not rehearse and not args.no_cpu_baseline:
         parity_ctx = driver.make_context(lib, d, fields=fields, radii=radii, bodies=bodies)
