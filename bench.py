@@ -199,26 +199,50 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     adi = 1 if d.eos == B.EOS_IDEAL else 0
 
+    torch_comm = None  # fallback: the transfers through torch.distributed (fargocpt_amd/parallel.py)
     if multi or rehearse:
         # the library's own RCCL communicator: slab 0 draws the id, the torch.distributed store carries it
-        if rehearse:
-            ctx.set_option("comm_loopback", 1)
-            uid = lib.comm_unique_id()
-        else:
-            box = [lib.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            uid = box[0]
-        ctx.comm_init(uid)
+        comm_error = ""
+        try:
+            if rehearse:
+                ctx.set_option("comm_loopback", 1)
+                uid = lib.comm_unique_id()
+            else:
+                box = [lib.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+            ctx.comm_init(uid)
+        except B.FcptError as err:   # e.g. librccl not loadable from the library: say so and keep the run alive
+            comm_error = str(err)
+        if multi:
+            # all ranks or none: a rank that could not create its communicator sends every rank to the fallback
+            bad = torch.tensor([1.0 if comm_error else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if bad.item() > 0:
+                sys.stderr.write(f"bench.py: rank {rank}: RCCL inside the library unavailable ({comm_error or 'another rank'}); "
+                                 "transfers through torch.distributed instead\n")
+                if not comm_error:
+                    ctx.comm_destroy()
+                from fargocpt_amd.parallel import DistributedSlab
+                torch_comm = DistributedSlab(ctx, device=dev)
+        elif comm_error:
+            raise SystemExit(f"bench.py: {comm_error}")
 
     # ---- one step ------------------------------------------------------------
     def run(n):
         # dt stays on the device: CFL [-> MIN over the slabs] -> policy -> step [-> ghost exchange] -> post,
         # enqueued by the library on one stream, no host synchronisation inside
-        ctx.run_steps(n, snap=False)
+        if torch_comm is not None:
+            for _ in range(n):
+                torch_comm.step_async()
+        else:
+            ctx.run_steps(n, snap=False)
 
     def pre_loop():
         # main()'s and sim::init's pre-loop calls (main.cpp:117,147, simulation.cpp:462-474)
-        if multi or rehearse:
+        if torch_comm is not None:
+            torch_comm.prepare()
+        elif multi or rehearse:
             ctx.calculate_timestep(ctx.cfl_allreduce())
             ctx.exchange()
             ctx.apply_boundary(0.0, False)
@@ -331,7 +355,9 @@ def main():
                        # N > 1: after the last step every slab's ghost rings equal its neighbours' rows [7,14) /
                        # [nr-14,nr-7) bit for bit, and all slabs hold the same clock (the MIN-reduced dt)
                        "ghost_rings_and_clock_consistent": exchange_ok,
-                       "communication": ("RCCL inside the library: grouped ncclSend/ncclRecv of 7 ghost rings per "
+                       "communication": ("torch.distributed fallback (isend/irecv + all_reduce on RCCL's stream)"
+                                         if torch_comm is not None else
+                                         "RCCL inside the library: grouped ncclSend/ncclRecv of 7 ghost rings per "
                                          "neighbour + ncclAllReduce(min) of dt, on the step's stream")
                        if (multi or rehearse) else "none (one slab)"},
             "rccl_world": rccl_world,

@@ -172,15 +172,22 @@ int comm_neighbour_exchange(Comm *c, int peer_inner, const double *send_inner, d
     if (peer_inner < 0 && peer_outer < 0)
         return FCPT_OK;
     NCHK(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
     if (peer_inner >= 0) {
-        NCHK(g_rccl.Send(send_inner, count, ncclDouble, peer_inner, c->comm, st));
-        NCHK(g_rccl.Recv(recv_inner, count, ncclDouble, peer_inner, c->comm, st));
+        r = g_rccl.Send(send_inner, count, ncclDouble, peer_inner, c->comm, st);
+        if (r == ncclSuccess)
+            r = g_rccl.Recv(recv_inner, count, ncclDouble, peer_inner, c->comm, st);
     }
-    if (peer_outer >= 0) {
-        NCHK(g_rccl.Send(send_outer, count, ncclDouble, peer_outer, c->comm, st));
-        NCHK(g_rccl.Recv(recv_outer, count, ncclDouble, peer_outer, c->comm, st));
+    if (peer_outer >= 0 && r == ncclSuccess) {
+        r = g_rccl.Send(send_outer, count, ncclDouble, peer_outer, c->comm, st);
+        if (r == ncclSuccess)
+            r = g_rccl.Recv(recv_outer, count, ncclDouble, peer_outer, c->comm, st);
     }
-    NCHK(g_rccl.GroupEnd());
+    const ncclResult_t e = g_rccl.GroupEnd(); // always closes the group, also after a failed call inside it
+    if (r != ncclSuccess || e != ncclSuccess) {
+        set_error("ghost exchange over RCCL failed: %s", g_rccl.GetErrorString(r != ncclSuccess ? r : e));
+        return FCPT_EHIP;
+    }
     return FCPT_OK;
 }
 
