@@ -770,7 +770,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     AL(qr, ns) AL(qphi, ns) AL(divv, ns) AL(trr, ns) AL(tpp, ns) AL(trp, nv) AL(qplus, ns) AL(qminus, ns)
     AL(rmpA, ns) AL(rmmA, ns) AL(lpA, ns) AL(lmA, ns) AL(sigA, ns) AL(eA, ns)
     AL(rmpB, ns) AL(rmmB, ns) AL(lpB, ns) AL(lmB, ns) AL(sigB, ns) AL(eB, ns)
-    AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1) AL(shift_jump, 1)
+    AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1) AL(shift_jump, 4)
     AL(cfl_part, (size_t)(nr + 256) * (size_t)((nphi + 255) / 256 + 1))
     AL(cfl_tickets, 32)
     P.ring_pstride = nphi / 32 + 4;

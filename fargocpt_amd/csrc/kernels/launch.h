@@ -137,7 +137,15 @@ static int source_rows(const Dev &P)
 {
     if (P.opt.source_rows > 0)
         return P.opt.source_rows;
-    return march_rows(P.nr + 1, (P.nphi + MARCH_VALID - 1) / MARCH_VALID, 24, 4);
+    int r = march_rows(P.nr + 1, (P.nphi + MARCH_VALID - 1) / MARCH_VALID, 24, 4);
+    // the boundary call folded into the kick needs the last chunk to hold rows nr-2 .. nr: a slightly longer chunk if
+    // the division leaves fewer than three rows over
+    for (int dr = 0; dr < 4; ++dr) {
+        const int chunks = (P.nr + 1 + r + dr - 1) / (r + dr);
+        if ((P.nr + 1) - (chunks - 1) * (r + dr) >= 3)
+            return r + dr;
+    }
+    return r;
 }
 static int transport_rows(const Dev &P)
 {
@@ -377,6 +385,40 @@ static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, 
 #undef MARCHC
 #undef MARCHK
 
+// k_transport_fallback: radial sweep, grid barrier, azimuthal march behind one idle check
+static void launch_fallback(const Dev &P, const Dev &Wm, hipStream_t st)
+{
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0, v = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 64;
+        n_cu = v;
+    }
+    ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
+    const Launch2D l = launch2d((P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS, P.nphi);
+    const int gx = (int)l.grid.x, gy = (int)l.grid.y;
+    const int tstride = 64 * 2 - (THETA_LO + THETA_HI);
+    const int tiles = (P.nphi + tstride - 1) / tstride;
+    const int rows = P.opt.theta_rows > 0 ? P.opt.theta_rows : THETA_ROWS;
+    const int nvb_theta = (((P.nr + rows - 1) / rows) * tiles + 3) / 4;
+    int blocks = gx * gy > nvb_theta ? gx * gy : nvb_theta;
+    blocks = blocks > FALLBACK_BLOCKS ? FALLBACK_BLOCKS : blocks;
+    blocks = blocks > n_cu ? n_cu : blocks; // the grid barrier needs every workgroup resident
+    const dim3 grid(blocks), block(256);
+    if (P.adiabatic) {
+        if (Wm.damp_in_step)
+            KLAUNCH(KID_TRANSPORT_RADIAL, (k_transport_fallback<true, true>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
+        else
+            KLAUNCH(KID_TRANSPORT_RADIAL, (k_transport_fallback<true, false>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
+    } else {
+        if (Wm.damp_in_step)
+            KLAUNCH(KID_TRANSPORT_RADIAL, (k_transport_fallback<false, true>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
+        else
+            KLAUNCH(KID_TRANSPORT_RADIAL, (k_transport_fallback<false, false>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
+    }
+}
 // the fused kernel runs, nothing is queued behind it, and there are chunks between the two ends
 bool transport_can_split(const Dev &P, bool shear_safe)
 {
@@ -470,9 +512,11 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
 #undef TFK2
         // behind it, the two-kernel form: its blocks return at once unless the fused kernel met
         // |Nshift[i] - Nshift[i-1]| > 1 (a time step beyond the FARGO shear limit)
-        if (fallback) {
+        if (P.opt.transport_fallback == 2) { // the two sweeps as two launches (the form of round 1)
             launch_radial(P, P.shift_jump, st);
             launch_theta_march(P, Wm, 2, 0, 0, P.shift_jump, st);
+        } else if (fallback) {
+            launch_fallback(P, Wm, st);
         }
         res.marched = tiles;
         res.sigma = Wm.sigma, res.energy = Wm.energy, res.vrad = Wm.vrad, res.vazi = Wm.vazi;

@@ -276,8 +276,10 @@ __global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, 
     if (lane == 0) {
         const double mean = acc / (double)P.nphi;
         P.vmean[i] = mean;
-        if (with_shift && i == 0)
-            *P.shift_jump = 0;
+        if (with_shift && i == 0) {
+            P.shift_jump[0] = 0; // raised by k_transport_fused if a ring pair is beyond its one-lane shift
+            P.shift_jump[1] = 0; // arrival counter of k_transport_fallback's grid barrier
+        }
         if (with_shift) {
             const double invdt = 1.0 / dt;
             const double Ntilde = mean * invr * dt * P.invdphi;
@@ -793,4 +795,44 @@ __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, cons
         return;
     for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x)
         transport_theta_march_block<C, ADI, DAMP, PER>(P, va_pre, vr_pre, in, tiles, rows, advance_clock, vb, nvb);
+}
+
+// The device-side fallback of k_transport_fused in ONE launch.  Its workgroups return at once unless that kernel raised
+// flag[0] (a ring pair beyond the one-lane shift: a dt beyond the FARGO shear limit, or a source step that changed
+// v_phi violently); then they do what k_transport_radial and k_transport_theta_march do, with a grid-wide barrier
+// between the two sweeps (the azimuthal march reads the momenta set B of neighbouring columns and rings).  The barrier
+// is safe because the grid is capped at the number of compute units (every workgroup is resident: 256 threads,
+// <= 128 VGPRs) and its spin is bounded: a workgroup that gives up reports the step as invalid (shear_error) instead
+// of hanging.  Only the rare path pays for the device-scope fences.
+template <bool ADI, bool DAMP>
+__global__ void __launch_bounds__(256) k_transport_fallback(const Dev P, const Dev W, ThetaSet in, int gx, int gy, int tiles,
+                                                           int rows, int nvb_theta, int *flag)
+{
+    if (!flag[0])
+        return;
+    for (int vb = blockIdx.x; vb < gx * gy; vb += gridDim.x)
+        transport_radial_block<true>(P, vb, gx, gx * gy);
+    __syncthreads();
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        __threadfence(); // this workgroup's part of set B is visible device-wide before it reports in
+        atomicAdd(&flag[1], 1);
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+            if (__hip_atomic_load(&flag[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x) {
+                ok = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        __threadfence();
+        if (!ok)
+            W.clk->shear_error = 2; // the other workgroups never arrived: the step is not computed
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok)
+        return;
+    for (int vb = blockIdx.x; vb < nvb_theta; vb += gridDim.x)
+        transport_theta_march_block<2, ADI, DAMP, false>(W, P.vazi, P.vrad, in, tiles, rows, 0, vb, nvb_theta);
 }
