@@ -118,9 +118,12 @@ void launch_source_fused(const Dev &P, hipStream_t st)
 // measured optimum is the default (24 rings at 2048 x 4096: the pre-roll of 4-5 rings per chunk against the tail of
 // the last blocks).  Smaller grids have fewer wavefronts than the GPU has slots: there the chain length is the
 // kernel time, so the chunks shrink until the wavefronts fill the slots once (1024 x 3072: 14-15 rings, 128 x 384: 4).
-static int march_rows(int nrows, int tiles, int rows_max, int preroll)
+// (measured, profiles/r02_sweep_rows_mid.txt: isothermal grids are fastest with the wavefronts filling the slots
+//  once, the ideal-EOS kernels -- 4 wavefronts per SIMD, more loads per ring -- with about 1.8 rounds: 1024 x 3072
+//  0.305 ms per step with 14-15 rings per chunk, 0.283 with 6-10)
+static int march_rows(int nrows, int tiles, int rows_max, int preroll, bool adiabatic)
 {
-    const double slots = 4096.0;
+    const double slots = adiabatic ? 7400.0 : 4096.0;
     int best = rows_max;
     double best_t = 1e300;
     for (int r = 4; r <= rows_max; ++r) {
@@ -137,7 +140,7 @@ static int source_rows(const Dev &P)
 {
     if (P.opt.source_rows > 0)
         return P.opt.source_rows;
-    int r = march_rows(P.nr + 1, (P.nphi + MARCH_VALID - 1) / MARCH_VALID, 24, 4);
+    int r = march_rows(P.nr + 1, (P.nphi + MARCH_VALID - 1) / MARCH_VALID, 24, 4, P.adiabatic != 0);
     // the boundary call folded into the kick needs the last chunk to hold rows nr-2 .. nr: a slightly longer chunk if
     // the division leaves fewer than three rows over
     for (int dr = 0; dr < 4; ++dr) {
@@ -153,7 +156,7 @@ static int transport_rows(const Dev &P)
         return P.opt.transport_rows;
     const int CF = 1; // cells per lane of the default kernel
     const int tstride = 64 * CF - (TfHalo<1>::lo + TfHalo<1>::hi);
-    return march_rows(P.nr, (P.nphi + tstride - 1) / tstride, TF_ROWS, 5);
+    return march_rows(P.nr, (P.nphi + tstride - 1) / tstride, TF_ROWS, 5, P.adiabatic != 0);
 }
 // whole source step in one marching pass (Nphi >= 128); returns 0 if not applicable, else +-segments (> 0: ring sums
 // of v_phi were left for the transport).  fold_bc: the caller's next call is apply_boundary_condition(final = false) on
