@@ -1,89 +1,48 @@
-// Context management and the device part of the C ABI (include/fargocpt_hip.h).
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <vector>
-
-#include "fcpt_comm.h"
-#include "fcpt_kernels.h"
+// Context management: creation and destruction, options, host <-> device transfers, bodies, initial physics and the
+// per-kernel profiler of the C ABI (include/fargocpt_hip.h).
+#include "fcpt_ctx.h"
 
 using namespace fcpt;
 
-#define HIPCHK(call)                                                                        \
-    do {                                                                                    \
-        hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess) {                                                             \
-            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return FCPT_EHIP;                                                               \
-        }                                                                                   \
-    } while (0)
+namespace fcpt {
 
-struct fcpt_ctx {
-    fcpt_desc d;
-    fcpt_split s;
-    HostGeometry geo;
-    std::vector<double> radii;
-    Dev P;
-    hipStream_t stream = nullptr;
-    std::vector<void *> allocs;
-    double *d_cs_ring = nullptr;
-    double *grid[FCPT_F_COUNT] = {};
-    DampRange damp[4][2]; // [vrad, vaz, sigma, energy][inner, outer]
-    bool potential_valid = false;
-    DevClock *h_clk = nullptr; // pinned staging copy
-    Profiler prof;
-    bool profiling = false;
-    bool fused_source = true;
-    int src_parts = 0; // segments of ring sums left by the last k_source_march
-    bool kick_energy_b = false;
-    bool kick_bc_folded = false; // the last kick applied the boundary conditions that follow it
-    bool ghosts_unknown = true;  // a state grid was uploaded since the last boundary call
-    // the dt of the next step is the CFL policy's (set by calculate_timestep*, consumed by the step):
-    // with CFL <= 0.8 that keeps it inside the FARGO shear limit
-    bool policy_dt_dev = false;
-    double policy_dt_host = -1.0; // the last kick left the energy in energy_b (marching source step, ideal EOS)
-    bool march_source = true;
-    bool stepped = false; // fcpt_step ran since the last fcpt_post
-    bool cfl_interior = false; // fcpt_cfl_begin evaluated the interior rings of the current state
-    bool damp_any = false;     // this slab holds rings of a damping zone
-    double *thermal_grid = nullptr; // storage of Dev::cfl_thermal (the view's pointer is null when the option is off)
-    bool thermal_valid = false;     // ... and it describes the current state (set by a marching-transport step)
-    bool damp_foldable = false; // ... and its damping can be folded into the transport (no "mean" target, Euler)
-    // fcpt_step_device_begin: the interior chunks of the transport run on `side` while the caller's stream
-    // marches the chunks with the neighbours' ghost rings, packs and sends them
-    hipStream_t side = nullptr;
-    hipEvent_t e_fork = nullptr, e_join = nullptr;
-    bool join_pending = false;
-    bool pressure_valid = false;
-    // leapfrog: bodies at the mid-step time (simulation.cpp:359-366)
-    bool has_mid = false;
-    double mx[FCPT_MAX_BODIES], my[FCPT_MAX_BODIES], mm[FCPT_MAX_BODIES], mrsm[FCPT_MAX_BODIES];
-    // radial slabs over RCCL (fcpt_comm_init): communicator, packed ghost-ring buffers [send inner, send outer,
-    // recv inner, recv outer], the device scalar of the MIN all-reduce, a stream for transfers that overlap the CFL
-    Comm *comm = nullptr;
-    double *xbuf[4] = {};
-    double *d_cfl = nullptr;
-    int peer_inner = -1, peer_outer = -1;
-    hipStream_t comm_stream = nullptr;
-    hipEvent_t e_packed = nullptr, e_received = nullptr;
-    int device = 0; // HIP device the context was created on
-    // fcpt_run_steps on launch-bound grids: a captured hipGraph of `graph_cycle` consecutive steps (the out-of-place
-    // transport swaps grid pointers, so the launch arguments repeat with period 2), replayed while the host-side state
-    // that decided the launches (the whole Dev view, the lazy-evaluation flags) is what it was at capture
-    hipGraphExec_t graph_exec = nullptr;
-    hipGraph_t graph = nullptr;
-    hipStream_t capture_stream = nullptr;
-    int graph_cycle = 0;
-    bool graph_failed = false;
-    Dev graph_P;
-    unsigned graph_flags = 0;
-};
+void drop_graph(fcpt_ctx *c)
+{
+    if (c->graph_exec)
+        (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph)
+        (void)hipGraphDestroy(c->graph);
+    c->graph_exec = nullptr;
+    c->graph = nullptr;
+    c->graph_cycle = 0;
+}
 
-#define DOB_ROWS_HOST 8 /* = DOB_ROWS of k_disk_on_body */
+// the caller's stream waits for the interior transport forked by fcpt_step_device_begin
+void join_side(fcpt_ctx *c)
+{
+    if (c->join_pending) {
+        (void)hipStreamWaitEvent(c->stream, c->e_join, 0);
+        c->join_pending = false;
+    }
+}
+
+int read_clock(fcpt_ctx *c, DevClock *out)
+{
+    join_side(c);
+    HIPCHK(hipMemcpyAsync(c->h_clk, c->P.clk, sizeof(DevClock), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = *c->h_clk;
+    if (out->shear_error) {
+        set_error("a step exceeded the FARGO shear limit (|Nshift[i]-Nshift[i-1]| > 1) with the option "
+                  "transport_fallback = 0, i.e. without the two-kernel transport queued behind the fused one; "
+                  "the state is invalid");
+        return FCPT_ESHEAR;
+    }
+    return FCPT_OK;
+}
+
+} // namespace fcpt
+
 namespace {
 
 int *option_slot(Options &o, const char *name)
@@ -123,43 +82,6 @@ void options_from_environment(Options &o)
 #undef X
 }
 
-// routes this thread's launches to the context's profiler while it is recording
-struct ProfScope {
-    Profiler *outer;
-    explicit ProfScope(fcpt_ctx *c) : outer(g_prof) { g_prof = c->profiling ? &c->prof : nullptr; }
-    ~ProfScope() { g_prof = outer; }
-};
-
-template <class T> int dev_alloc(fcpt_ctx *c, T **p, size_t n)
-{
-    void *q = nullptr;
-    hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
-    if (e != hipSuccess) {
-        set_error("hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
-        return FCPT_ENOMEM;
-    }
-    e = hipMemset(q, 0, (n ? n : 1) * sizeof(T));
-    if (e != hipSuccess) {
-        set_error("hipMemset failed: %s", hipGetErrorString(e));
-        return FCPT_EHIP;
-    }
-    c->allocs.push_back(q);
-    *p = (T *)q;
-    return FCPT_OK;
-}
-
-template <class T> int dev_upload_raw(fcpt_ctx *c, const T **dst, const std::vector<T> &src)
-{
-    T *p = nullptr;
-    if (int e = dev_alloc(c, &p, src.size()))
-        return e;
-    if (hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
-        set_error("hipMemcpy of a per-ring table failed");
-        return FCPT_EHIP;
-    }
-    *dst = p;
-    return FCPT_OK;
-}
 int dev_upload(fcpt_ctx *c, const double **dst, const std::vector<double> &src)
 {
     double *p = nullptr;
@@ -218,26 +140,6 @@ DampRange damp_range(const fcpt_ctx *c, int is_vector, int type, int outer)
     return r;
 }
 
-void drop_graph(fcpt_ctx *c)
-{
-    if (c->graph_exec)
-        (void)hipGraphExecDestroy(c->graph_exec);
-    if (c->graph)
-        (void)hipGraphDestroy(c->graph);
-    c->graph_exec = nullptr;
-    c->graph = nullptr;
-    c->graph_cycle = 0;
-}
-
-// the caller's stream waits for the interior transport forked by fcpt_step_device_begin
-void join_side(fcpt_ctx *c)
-{
-    if (c->join_pending) {
-        (void)hipStreamWaitEvent(c->stream, c->e_join, 0);
-        c->join_pending = false;
-    }
-}
-
 // the context's derived switches after its options changed (fcpt_create, fcpt_set_option)
 void apply_options(fcpt_ctx *c, bool at_create = true)
 {
@@ -270,25 +172,6 @@ void apply_options(fcpt_ctx *c, bool at_create = true)
     }
 }
 
-// boundary_conditions.cpp:65-114
-void apply_boundary_view(fcpt_ctx *c, const Dev &P, bool final, bool damping_done = false)
-{
-    if (final && c->d.damping && !damping_done) {
-        // damping.cpp:754-774, order of damping_vector: vrad, vaz, sigma, energy
-        for (int o = 0; o < 2; ++o)
-            launch_damping(P, P.vrad, P.vrad0, P.Rinf.p, c->damp[0][o], 0, c->stream);
-        for (int o = 0; o < 2; ++o)
-            launch_damping(P, P.vazi, P.vazi0, P.Rmed.p, c->damp[1][o], 0, c->stream);
-        for (int o = 0; o < 2; ++o)
-            launch_damping(P, P.sigma, P.sigma0, P.Rmed.p, c->damp[2][o], 1, c->stream);
-        if (P.adiabatic)
-            for (int o = 0; o < 2; ++o)
-                launch_damping(P, P.energy, P.energy0, P.Rmed.p, c->damp[3][o], 0, c->stream);
-    }
-    launch_boundary(P, c->stream);
-}
-void apply_boundary(fcpt_ctx *c, bool final) { apply_boundary_view(c, c->P, final); }
-
 int copy_initial_values(fcpt_ctx *c)
 {
     const Dev &P = c->P;
@@ -298,212 +181,6 @@ int copy_initial_values(fcpt_ctx *c)
     HIPCHK(hipMemcpyAsync(P.sigma0, P.sigma, ns, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(P.energy0, P.energy, ns, hipMemcpyDeviceToDevice, c->stream));
     return FCPT_OK;
-}
-
-int read_clock(fcpt_ctx *c, DevClock *out)
-{
-    join_side(c);
-    HIPCHK(hipMemcpyAsync(c->h_clk, c->P.clk, sizeof(DevClock), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    *out = *c->h_clk;
-    if (out->shear_error) {
-        set_error("a step exceeded the FARGO shear limit (|Nshift[i]-Nshift[i-1]| > 1) with the option "
-                  "transport_fallback = 0, i.e. without the two-kernel transport queued behind the fused one; "
-                  "the state is invalid");
-        return FCPT_ESHEAR;
-    }
-    return FCPT_OK;
-}
-
-// isothermal pressure is Sigma c_s^2 with c_s fixed per ring: the marching source kernel forms
-// it in registers, so the grid is only materialised for callers that ask for it
-// (ideal EOS with the marching source step: the same holds for T, c_s, H and nu)
-void ensure_pressure(fcpt_ctx *c)
-{
-    if (!c->pressure_valid) {
-        if (c->P.adiabatic)
-            launch_derived(c->P, c->stream);
-        else
-            launch_pressure(c->P, c->stream);
-        c->pressure_valid = true;
-    }
-}
-
-// one gas "kick" (source terms, artificial viscosity, viscosity, SubStep3) with the step length
-// currently in the device clock.  Returns true if the result is in (vrad_b, vazi_b).
-bool enqueue_kick(fcpt_ctx *c, bool fold_bc = false)
-{
-    const Dev &P = c->P;
-    hipStream_t st = c->stream;
-    c->kick_bc_folded = false;
-    if (c->fused_source) {
-        // one pass: (v[, e]) -> (v_b[, e_b]); fold_bc: and the boundary call that follows the first kick of a step
-        const int segs = c->march_source ? launch_source_march(P, st, fold_bc, &c->kick_bc_folded) : 0;
-        c->src_parts = segs > 0 ? segs : 0;
-        c->kick_energy_b = segs != 0 && P.adiabatic;
-        if (!segs) {
-            ensure_pressure(c);
-            launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
-            launch_recalculate_viscosity(P, st);
-            launch_viscous_fused(P, st);         // (v) -> (v_b)
-            if (P.adiabatic)
-                launch_substep3_after_fused(P, st);
-        }
-        return true;
-    }
-    ensure_pressure(c);
-    launch_source(P, st);
-    launch_artificial_viscosity(P, st);
-    launch_recalculate_viscosity(P, st);
-    launch_stress(P, st);
-    launch_viscous_update(P, st);
-    if (P.adiabatic)
-        launch_substep3(P, 1, st);
-    return false;
-}
-
-void enqueue_potential(fcpt_ctx *c, bool midstep)
-{
-    Dev &P = c->P;
-    if (midstep && P.adiabatic && P.lazy_derived) {
-        // the mid-step potential of step_LeapFrog sees the scale height of the first kick (left in the
-        // grid by k_source_march_adi), not one derived from the transported state
-        Dev M = P;
-        M.lazy_derived = 0;
-        if (c->has_mid)
-            for (int k = 0; k < P.nbodies; ++k) {
-                M.bx[k] = c->mx[k];
-                M.by[k] = c->my[k];
-                M.bm[k] = c->mm[k];
-                M.brsm[k] = c->mrsm[k];
-            }
-        launch_potential(M, c->stream);
-        c->potential_valid = false;
-        return;
-    }
-    if (midstep && c->has_mid) {
-        Dev M = P;
-        for (int k = 0; k < P.nbodies; ++k) {
-            M.bx[k] = c->mx[k];
-            M.by[k] = c->my[k];
-            M.bm[k] = c->mm[k];
-            M.brsm[k] = c->mrsm[k];
-        }
-        launch_potential(M, c->stream);
-        c->potential_valid = false; // the grid now holds the mid-step potential
-        return;
-    }
-    if (P.inline_potential) { // k_source_march_adi evaluates it ring by ring; the grid is only filled on request
-        c->potential_valid = false;
-        return;
-    }
-    if (P.adiabatic || !c->potential_valid) {
-        launch_potential(P, c->stream); // CalculateNbodyPotential; static when H and the bodies are
-        c->potential_valid = true;
-    }
-}
-
-// the gas part of step_Euler up to Transport (simulation.cpp:167-217), or of step_LeapFrog
-// (simulation.cpp:316-393): kick 1/2 (dt/2), drift (dt), kick 2/2 (dt/2).  `dt_dev`: the step
-// length is already in the device clock (device-resident dt), else `dt` is written there.
-void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool split = false)
-{
-    join_side(c);
-    c->cfl_interior = false;
-    const Dev &P = c->P;
-    hipStream_t st = c->stream;
-    const bool frog = c->d.integrator == FCPT_INTEGRATOR_LEAPFROG;
-    if (frog)
-        launch_clock_scale_dt(P.clk, dt_dev ? 1 : 0, dt, 0.5, st); // dt <- step/2, keeps step in cfl_dt
-    else if (!dt_dev)
-        launch_clock_set_dt(P.clk, dt, st);
-    enqueue_potential(c, false);
-    // (after an upload of a state grid the ghost rings may not satisfy the boundary conditions yet: the folded form
-    //  rewrites Sigma's ghost ring while neighbouring wavefronts may still read it -- harmless only when the values
-    //  are the ones already there, so that one step takes the separate launch)
-    const bool in_b = enqueue_kick(c, !c->ghosts_unknown);
-    c->ghosts_unknown = false;
-    Dev Q = P; // view with the post-kick velocities
-    if (in_b) {
-        Q.vrad = P.vrad_b;
-        Q.vazi = P.vazi_b;
-    }
-    if (c->kick_energy_b)
-        Q.energy = P.energy_b;
-    c->kick_energy_b = false;
-    Q.src_ring_nparts = in_b ? c->src_parts : 0; // ring sums of v_phi left by k_source_march
-    c->src_parts = 0;
-    if (!c->kick_bc_folded) // (else the source march applied it on its edge chunks)
-        apply_boundary_view(c, Q, false);
-    c->kick_bc_folded = false;
-    if (frog)
-        launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step (saved in cfl_dt)
-    launch_massflow(Q, st); // WriteMassFlow: what this Transport() carries through the interfaces
-    TransportResult tr;
-    if (split && !frog && transport_can_split(Q, shear_safe) && c->side) {
-        launch_shift_means(Q, st);
-        (void)hipEventRecord(c->e_fork, st);
-        (void)hipStreamWaitEvent(c->side, c->e_fork, 0);
-        (void)launch_transport(Q, P, c->side, TRANSPORT_INTERIOR);
-        (void)hipEventRecord(c->e_join, c->side);
-        tr = launch_transport(Q, P, st, TRANSPORT_EDGES);
-        c->join_pending = true;
-    } else {
-        tr = launch_transport(Q, P, st);
-    }
-    if (!tr.marched)
-        launch_clock_advance(P.clk, st);
-    // a marching transport kernel stored the cell-local CFL terms with the new Sigma and e; they stay those of the
-    // final state if nothing but boundary rings and ghost rows changes before the next CFL reduction (the wave
-    // damping folded into that kernel, or no damping zone on this slab)
-    c->thermal_valid = P.cfl_thermal != nullptr && tr.marched > 0 && !frog && (!c->damp_any || P.damp_in_step != 0);
-    // the marching transport is out of place: the new state may sit in the scratch twins
-    if (tr.sigma != c->P.sigma)
-        std::swap(c->P.sigma, c->P.sigA);
-    if (tr.energy != c->P.energy)
-        std::swap(c->P.energy, c->P.eA);
-    if (tr.vrad != c->P.vrad)
-        std::swap(c->P.vrad, c->P.vrad_b);
-    if (tr.vazi != c->P.vazi)
-        std::swap(c->P.vazi, c->P.vazi_b);
-    c->grid[FCPT_F_SIGMA] = c->P.sigma;
-    c->grid[FCPT_F_VRAD] = c->P.vrad;
-    c->grid[FCPT_F_VAZI] = c->P.vazi;
-    c->grid[FCPT_F_ENERGY] = c->P.energy;
-    if (frog) {
-        launch_clock_scale_dt(P.clk, 2, 0.0, 0.5, st); // dt <- step/2
-        enqueue_potential(c, true);
-        c->pressure_valid = false; // compute_pressure(data), simulation.cpp:378
-        if (P.adiabatic && !P.lazy_derived)
-            ensure_pressure(c);
-        c->P.kick_time_shift = 1; // SubStep3 of the second kick runs at midstep_time (simulation.cpp:388)
-        const bool home = enqueue_kick(c);
-        c->P.kick_time_shift = 0;
-        if (home) { // result in the *_b buffers: bring it home
-            const size_t ns = (size_t)P.nr * P.nphi * sizeof(double), nv = (size_t)(P.nr + 1) * P.nphi * sizeof(double);
-            (void)hipMemcpyAsync(P.vrad, P.vrad_b, nv, hipMemcpyDeviceToDevice, st);
-            (void)hipMemcpyAsync(P.vazi, P.vazi_b, ns, hipMemcpyDeviceToDevice, st);
-            if (c->kick_energy_b)
-                (void)hipMemcpyAsync(P.energy, P.energy_b, ns, hipMemcpyDeviceToDevice, st);
-            c->kick_energy_b = false;
-        }
-        launch_clock_scale_dt(P.clk, 2, 0.0, 1.0, st); // dt <- step, for the damping of the final boundary call
-    }
-    c->stepped = true;
-}
-
-void enqueue_post(fcpt_ctx *c)
-{
-    join_side(c);
-    // the damping of the final boundary call was applied by k_velocities when damp_in_step
-    apply_boundary_view(c, c->P, true, c->P.damp_in_step != 0 && c->stepped);
-    c->stepped = false;
-    if (c->P.adiabatic && !c->P.lazy_derived) {
-        launch_derived(c->P, c->stream);
-        c->pressure_valid = true;
-    } else {
-        c->pressure_valid = false; // recalculate_derived_disk_quantities: P only, evaluated lazily
-    }
 }
 
 } // namespace
@@ -1274,17 +951,6 @@ int fcpt_init_physics(fcpt_ctx *c)
     return FCPT_OK;
 }
 
-} // extern "C"
-namespace {
-void enqueue_cfl(fcpt_ctx *c, int apply_policy)
-{
-    join_side(c);
-    c->P.cfl_thermal_on = c->thermal_valid ? 1 : 0;
-    launch_cfl(c->P, apply_policy, c->stream, c->cfl_interior);
-    c->cfl_interior = false;
-}
-} // namespace
-extern "C" {
 
 // recalculate_derived_disk_quantities (SourceEuler.cpp:225-249) after the state grids were replaced from outside
 int fcpt_recalculate_derived(fcpt_ctx *c)
@@ -1304,402 +970,6 @@ int fcpt_recalculate_derived(fcpt_ctx *c)
         c->pressure_valid = false; // evaluated lazily
     }
     HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-// condition_cfl for the rings that neither the ghost exchange nor the boundary kernels touch, to be queued between
-// fcpt_exchange_pack and the wait for the neighbours' rings: it runs while they are on the wire.  The next
-// fcpt_cfl / fcpt_cfl_device evaluates the remaining rings and reduces.  A no-op (the whole CFL runs later)
-// whenever that split would not see the final state: damping outside the step kernels, narrow rings, ...
-int fcpt_cfl_begin(fcpt_ctx *c)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    join_side(c);
-    c->cfl_interior = false;
-    const bool state_final = c->stepped && (!c->damp_any || c->P.damp_in_step != 0); // fcpt_post will not damp
-    if (!state_final)
-        return FCPT_OK;
-    if (c->P.opt.cfl_split == 0)
-        return FCPT_OK;
-    ProfScope prof_scope(c);
-    c->P.cfl_thermal_on = c->thermal_valid ? 1 : 0;
-    c->cfl_interior = launch_cfl_interior(c->P, c->stream);
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-int fcpt_cfl(fcpt_ctx *c, double *dt_local)
-{
-    if (!c || !dt_local)
-        return FCPT_EINVAL;
-    ProfScope prof_scope(c);
-    enqueue_cfl(c, 0);
-    HIPCHK(hipGetLastError());
-    DevClock k;
-    if (int rc = read_clock(c, &k))
-        return rc;
-    double v;
-    std::memcpy(&v, &k.cfl_bits, sizeof(v));
-    *dt_local = v;
-    return FCPT_OK;
-}
-
-int fcpt_cfl_device(fcpt_ctx *c, double *d_dt_local)
-{
-    if (!c || !d_dt_local)
-        return FCPT_EINVAL;
-    ProfScope prof_scope(c);
-    enqueue_cfl(c, 0);
-    launch_clock_export_cfl(c->P.clk, d_dt_local, c->stream);
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-int fcpt_calculate_timestep_device(fcpt_ctx *c, const double *d_cfl_global)
-{
-    if (c && !d_cfl_global)
-        d_cfl_global = c->d_cfl; // what fcpt_cfl_allreduce left
-    if (!c || !d_cfl_global)
-        return FCPT_EINVAL;
-    ProfScope prof_scope(c);
-    launch_clock_policy_ptr(c->P.clk, c->d.cfl_max_var, d_cfl_global, c->stream);
-    c->policy_dt_dev = true;
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-int fcpt_step_device(fcpt_ctx *c)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    ProfScope prof_scope(c);
-    enqueue_step(c, true, 0.0, c->policy_dt_dev && c->d.cfl <= 0.8);
-    c->policy_dt_dev = false;
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-// fcpt_step_device for slabs with neighbours: the chunks of the transport that hold the rings the neighbours are
-// waiting for (rows [7,14), [nr-14,nr-7)) are marched on the caller's stream, all others on an internal stream,
-// so that fcpt_exchange_pack and the transfers queued next run under the interior chunks.  Until
-// fcpt_step_device_end only fcpt_exchange_pack may be called.
-int fcpt_step_device_begin(fcpt_ctx *c)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    if (!c->side) {
-        HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->e_join, hipEventDisableTiming));
-    }
-    ProfScope prof_scope(c);
-    enqueue_step(c, true, 0.0, c->policy_dt_dev && c->d.cfl <= 0.8, true);
-    c->policy_dt_dev = false;
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-int fcpt_step_device_end(fcpt_ctx *c)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    join_side(c);
-    return FCPT_OK;
-}
-
-int fcpt_post_device(fcpt_ctx *c)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    join_side(c);
-    ProfScope prof_scope(c);
-    enqueue_post(c);
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-int fcpt_calculate_timestep(fcpt_ctx *c, double cfl_dt_global, double *dt)
-{
-    if (!c || !dt)
-        return FCPT_EINVAL;
-    launch_clock_policy(c->P.clk, c->d.cfl_max_var, 0, cfl_dt_global, c->stream);
-    DevClock k;
-    if (int rc = read_clock(c, &k))
-        return rc;
-    *dt = k.last_dt;
-    c->policy_dt_host = k.last_dt;
-    return FCPT_OK;
-}
-
-int fcpt_snap_to_monitor(const fcpt_ctx *cc, double cfl_dt, double *step_dt)
-{
-    fcpt_ctx *c = const_cast<fcpt_ctx *>(cc);
-    if (!c || !step_dt)
-        return FCPT_EINVAL;
-    DevClock k;
-    if (int rc = read_clock(c, &k))
-        return rc;
-    // simulation.cpp:528-540
-    const double time_next_monitor = (k.n_monitor + 1) * c->d.monitor_timestep;
-    const double time_left_till_write = time_next_monitor - k.time;
-    const bool overshoot = cfl_dt > time_left_till_write;
-    const double dt_stretch_factor = 0.05;
-    const bool almost_there = time_left_till_write < cfl_dt * (1 + dt_stretch_factor);
-    *step_dt = (overshoot || almost_there) ? time_left_till_write : cfl_dt;
-    return FCPT_OK;
-}
-
-int fcpt_step(fcpt_ctx *c, double dt)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    ProfScope prof_scope(c);
-    enqueue_step(c, false, dt, c->policy_dt_host > 0.0 && dt <= c->policy_dt_host * (1.0 + 1e-12) && c->d.cfl <= 0.8);
-    c->policy_dt_host = -1.0;
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-int fcpt_post(fcpt_ctx *c, double dt)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    ProfScope prof_scope(c);
-    launch_clock_set_dt(c->P.clk, dt, c->stream);
-    enqueue_post(c);
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-int fcpt_apply_boundary(fcpt_ctx *c, double dt, int32_t final)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    join_side(c);
-    ProfScope prof_scope(c);
-    launch_clock_set_dt(c->P.clk, dt, c->stream);
-    if (final && c->damp_any)
-        c->thermal_valid = false; // the wave damping changes Sigma and e of the damping zones
-    apply_boundary(c, final != 0);
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-int fcpt_exchange_count(const fcpt_ctx *c, uint64_t *count)
-{
-    if (!c || !count)
-        return FCPT_EINVAL;
-    *count = (uint64_t)(c->d.eos == FCPT_EOS_IDEAL ? 4 : 3) * c->d.nphi * FCPT_OVERLAP;
-    return FCPT_OK;
-}
-
-} // extern "C"
-namespace {
-// device buffers (RCCL sends them in place) go through one copy kernel; host buffers (slabs of one process,
-// staged exchange) through hipMemcpyAsync per field and side
-bool exchange_on_device(const void *p)
-{
-    if (!p)
-        return true;
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError(); // plain host memory: not an error here
-        return false;
-    }
-    return a.type == hipMemoryTypeDevice;
-}
-int exchange_memcpy(fcpt_ctx *c, double *inner, double *outer, int unpack)
-{
-    const Dev &P = c->P;
-    const size_t l = (size_t)FCPT_OVERLAP * P.nphi, lb = l * sizeof(double);
-    const size_t row_in = unpack ? 0 : l, row_out = (size_t)(P.nr - (unpack ? 1 : 2) * FCPT_OVERLAP) * P.nphi;
-    double *field[4] = {P.sigma, P.vrad, P.vazi, P.energy};
-    const int nq = P.adiabatic ? 4 : 3;
-    for (int q = 0; q < nq; ++q) {
-        if (inner)
-            HIPCHK(unpack ? hipMemcpyAsync(field[q] + row_in, inner + q * l, lb, hipMemcpyDefault, c->stream)
-                          : hipMemcpyAsync(inner + q * l, field[q] + row_in, lb, hipMemcpyDefault, c->stream));
-        if (outer)
-            HIPCHK(unpack ? hipMemcpyAsync(field[q] + row_out, outer + q * l, lb, hipMemcpyDefault, c->stream)
-                          : hipMemcpyAsync(outer + q * l, field[q] + row_out, lb, hipMemcpyDefault, c->stream));
-    }
-    return FCPT_OK;
-}
-} // namespace
-extern "C" {
-
-// commbound.cpp:108-125: rows [7,14) -> inner neighbour, rows [nr-14,nr-7) -> outer
-int fcpt_exchange_pack(fcpt_ctx *c, double *send_inner, double *send_outer)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    if (c->P.nr < 2 * FCPT_OVERLAP)
-        return FCPT_EINVAL;
-    if (!exchange_on_device(send_inner) || !exchange_on_device(send_outer))
-        return exchange_memcpy(c, send_inner, send_outer, 0);
-    if (send_inner || send_outer)
-        launch_exchange_copy(c->P, send_inner, send_outer, 0, c->stream);
-    return FCPT_OK;
-}
-
-// commbound.cpp:163-180: inner neighbour's data -> rows [0,7), outer's -> rows [nr-7,nr)
-int fcpt_exchange_unpack(fcpt_ctx *c, const double *recv_inner, const double *recv_outer)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    if (c->P.nr < 2 * FCPT_OVERLAP)
-        return FCPT_EINVAL;
-    join_side(c);
-    if (!exchange_on_device(recv_inner) || !exchange_on_device(recv_outer))
-        return exchange_memcpy(c, const_cast<double *>(recv_inner), const_cast<double *>(recv_outer), 1);
-    if (recv_inner || recv_outer)
-        launch_exchange_copy(c->P, const_cast<double *>(recv_inner), const_cast<double *>(recv_outer), 1, c->stream);
-    return FCPT_OK;
-}
-
-// ---- radial slabs over RCCL ----------------------------------------------------------------------------------
-
-int fcpt_comm_unique_id(void *id128)
-{
-    const int rc = comm_unique_id(id128);
-    return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
-}
-
-int fcpt_comm_init(fcpt_ctx *c, const void *id128)
-{
-    if (!c || !id128)
-        return FCPT_EINVAL;
-    if (c->comm) {
-        set_error("fcpt_comm_init: the context already has a communicator");
-        return FCPT_EINVAL;
-    }
-    const bool loopback = c->P.opt.comm_loopback != 0;
-    if (!loopback && c->P.nr < 2 * FCPT_OVERLAP && c->d.nranks > 1)
-        return FCPT_ESPLIT;
-    HIPCHK(hipSetDevice(c->device));
-    // rehearsal on one GPU: a communicator of one rank whose slab sends its ghost rings to itself
-    const int rank = loopback ? 0 : c->d.rank, nranks = loopback ? 1 : c->d.nranks;
-    if (int rc = comm_create(id128, rank, nranks, &c->comm))
-        return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
-    c->peer_inner = loopback ? 0 : (c->s.is_first ? -1 : rank - 1);
-    c->peer_outer = loopback ? 0 : (c->s.is_last ? -1 : rank + 1);
-    uint64_t cnt = 0;
-    (void)fcpt_exchange_count(c, &cnt);
-    int rc = FCPT_OK;
-    for (int k = 0; k < 4 && !rc; ++k)
-        rc = dev_alloc(c, &c->xbuf[k], (size_t)cnt);
-    if (!rc)
-        rc = dev_alloc(c, &c->d_cfl, 1);
-    if (rc)
-        return rc;
-    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->e_packed, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->e_received, hipEventDisableTiming));
-    return FCPT_OK;
-}
-
-int fcpt_comm_destroy(fcpt_ctx *c)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    if (c->comm) {
-        join_side(c);
-        (void)hipStreamSynchronize(c->stream);
-        if (c->comm_stream)
-            (void)hipStreamSynchronize(c->comm_stream);
-        comm_destroy(c->comm);
-        c->comm = nullptr;
-    }
-    if (c->comm_stream)
-        (void)hipStreamDestroy(c->comm_stream);
-    if (c->e_packed)
-        (void)hipEventDestroy(c->e_packed);
-    if (c->e_received)
-        (void)hipEventDestroy(c->e_received);
-    c->comm_stream = nullptr;
-    c->e_packed = c->e_received = nullptr;
-    return FCPT_OK; // the ghost buffers go with the context
-}
-
-} // extern "C"
-namespace {
-// commbound.cpp:98-182
-int enqueue_exchange(fcpt_ctx *c)
-{
-    if (!c->comm) {
-        set_error("fcpt_exchange needs fcpt_comm_init");
-        return FCPT_EINVAL;
-    }
-    if (c->peer_inner < 0 && c->peer_outer < 0)
-        return FCPT_OK; // a single slab: CommunicateBoundaries returns at once (commbound.cpp:104)
-    join_side(c);
-    double *s_in = c->peer_inner >= 0 ? c->xbuf[0] : nullptr, *s_out = c->peer_outer >= 0 ? c->xbuf[1] : nullptr;
-    double *r_in = c->peer_inner >= 0 ? c->xbuf[2] : nullptr, *r_out = c->peer_outer >= 0 ? c->xbuf[3] : nullptr;
-    uint64_t cnt = 0;
-    (void)fcpt_exchange_count(c, &cnt);
-    launch_exchange_copy(c->P, s_in, s_out, 0, c->stream);
-    int rc;
-    if (c->P.opt.comm_overlap != 0) {
-        // transfers on the communication stream; under them, on the context's stream, the CFL terms of the rings
-        // that neither the unpack nor the boundary kernels write (fcpt_cfl_begin)
-        HIPCHK(hipEventRecord(c->e_packed, c->stream));
-        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->e_packed, 0));
-        rc = comm_neighbour_exchange(c->comm, c->peer_inner, s_in, r_in, c->peer_outer, s_out, r_out, (size_t)cnt,
-                                     c->comm_stream);
-        HIPCHK(hipEventRecord(c->e_received, c->comm_stream));
-        if (!rc)
-            rc = fcpt_cfl_begin(c);
-        HIPCHK(hipStreamWaitEvent(c->stream, c->e_received, 0));
-    } else {
-        rc = comm_neighbour_exchange(c->comm, c->peer_inner, s_in, r_in, c->peer_outer, s_out, r_out, (size_t)cnt,
-                                     c->stream);
-    }
-    if (rc)
-        return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
-    launch_exchange_copy(c->P, r_in, r_out, 1, c->stream);
-    return FCPT_OK;
-}
-
-// cfl.cpp:185-379 with the result left in c->d_cfl
-int enqueue_cfl_allreduce(fcpt_ctx *c)
-{
-    enqueue_cfl(c, 0);
-    launch_clock_export_cfl(c->P.clk, c->d_cfl, c->stream);
-    const int rc = comm_allreduce_min(c->comm, c->d_cfl, c->stream);
-    return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
-}
-} // namespace
-extern "C" {
-
-int fcpt_exchange(fcpt_ctx *c)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    ProfScope prof_scope(c);
-    if (int rc = enqueue_exchange(c))
-        return rc;
-    HIPCHK(hipGetLastError());
-    return FCPT_OK;
-}
-
-int fcpt_cfl_allreduce(fcpt_ctx *c, double *dt_global)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    if (!c->comm) {
-        set_error("fcpt_cfl_allreduce needs fcpt_comm_init");
-        return FCPT_EINVAL;
-    }
-    ProfScope prof_scope(c);
-    if (int rc = enqueue_cfl_allreduce(c))
-        return rc;
-    HIPCHK(hipGetLastError());
-    if (dt_global) {
-        HIPCHK(hipMemcpyAsync(&c->h_clk->cfl_dt, c->d_cfl, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        *dt_global = c->h_clk->cfl_dt;
-    }
     return FCPT_OK;
 }
 
@@ -1742,188 +1012,6 @@ int fcpt_profile_stop(fcpt_ctx *c, double *ms_total, int64_t *launches)
         ms_total[p.ids[n]] += ms;
         launches[p.ids[n]] += 1;
     }
-    return FCPT_OK;
-}
-
-} // extern "C"
-namespace {
-unsigned launch_flags(const fcpt_ctx *c)
-{
-    return (c->potential_valid ? 1u : 0u) | (c->pressure_valid ? 2u : 0u) | (c->stepped ? 4u : 0u) |
-           (c->cfl_interior ? 8u : 0u) | (c->kick_energy_b ? 16u : 0u) | (c->fused_source ? 32u : 0u) |
-           (c->march_source ? 64u : 0u) | (c->has_mid ? 128u : 0u) | (c->join_pending ? 256u : 0u) |
-           (c->thermal_valid ? 512u : 0u) |
-           ((unsigned)c->src_parts << 12);
-}
-bool graph_wanted(const fcpt_ctx *c)
-{
-    if (c->profiling || c->graph_failed || c->comm)
-        return false;
-    if (c->P.opt.graph_steps >= 0)
-        return c->P.opt.graph_steps != 0;
-    // launch-bound grids: the kernels of a step are shorter than the host's launch calls
-    return (long long)c->P.nr * c->P.nphi <= 131072;
-}
-// one iteration of the device-resident loop: CFL reduction -> policy kernel -> step -> post
-void enqueue_device_step(fcpt_ctx *c)
-{
-    enqueue_cfl(c, 1);
-    enqueue_step(c, true, 0.0, c->d.cfl <= 0.8);
-    enqueue_post(c);
-}
-// capture `cycle` steps; true if the host-side state is back where it started (the graph can be replayed)
-bool capture_graph(fcpt_ctx *c, int cycle)
-{
-    if (!c->capture_stream && hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess)
-        return false;
-    const Dev P0 = c->P;
-    const unsigned f0 = launch_flags(c);
-    hipStream_t user = c->stream;
-    c->stream = c->capture_stream;
-    bool ok = hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-    if (ok) {
-        for (int n = 0; n < cycle; ++n)
-            enqueue_device_step(c);
-        hipGraph_t g = nullptr;
-        ok = hipStreamEndCapture(c->capture_stream, &g) == hipSuccess && g != nullptr;
-        c->graph = g;
-    }
-    c->stream = user;
-    (void)hipGetLastError();
-    const bool periodic = std::memcmp(&P0, &c->P, sizeof(Dev)) == 0 && f0 == launch_flags(c);
-    if (ok && periodic)
-        ok = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0) == hipSuccess;
-    if (!ok || !periodic) {
-        // nothing was executed during the capture: put the host-side view back and step without a graph
-        c->P = P0;
-        c->grid[FCPT_F_SIGMA] = c->P.sigma;
-        c->grid[FCPT_F_VRAD] = c->P.vrad;
-        c->grid[FCPT_F_VAZI] = c->P.vazi;
-        c->grid[FCPT_F_ENERGY] = c->P.energy;
-        c->potential_valid = f0 & 1u;
-        c->pressure_valid = f0 & 2u;
-        c->stepped = f0 & 4u;
-        c->cfl_interior = f0 & 8u;
-        c->kick_energy_b = f0 & 16u;
-        c->thermal_valid = f0 & 512u;
-        c->src_parts = (int)(f0 >> 12);
-        drop_graph(c);
-        return false;
-    }
-    c->graph_cycle = cycle;
-    c->graph_P = c->P;
-    c->graph_flags = f0;
-    return true;
-}
-} // namespace
-extern "C" {
-
-// sim::run's loop (simulation.cpp:515-553) for a single slab.
-int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
-{
-    if (!c)
-        return FCPT_EINVAL;
-    ProfScope prof_scope(c);
-    int64_t n = 0;
-    const bool slabs = c->comm && (c->peer_inner >= 0 || c->peer_outer >= 0); // this slab has neighbours
-    if (slabs && !snap) {
-        // several slabs, dt never leaves the device: CFL -> MIN over the slabs (cfl.cpp:379) -> policy kernel -> step
-        // -> ghost exchange (simulation.cpp:236) -> post, all on one stream
-        for (; n < nsteps; ++n) {
-            if (int rc = enqueue_cfl_allreduce(c))
-                return rc;
-            launch_clock_policy_ptr(c->P.clk, c->d.cfl_max_var, c->d_cfl, c->stream);
-            enqueue_step(c, true, 0.0, c->d.cfl <= 0.8);
-            if (int rc = enqueue_exchange(c))
-                return rc;
-            enqueue_post(c);
-        }
-        HIPCHK(hipGetLastError());
-    } else if (slabs) {
-        // monitor-time snapping: the reduced dt comes to the host, as in sim::run
-        const double t_final = (double)c->d.nsnapshots * c->d.nmonitor * c->d.monitor_timestep;
-        for (; n < nsteps; ++n) {
-            DevClock k;
-            if (int rc = read_clock(c, &k))
-                return rc;
-            if (t_final > 0 && !(k.time < t_final))
-                break;
-            double cfl_dt, dt, step_dt;
-            if (int rc = fcpt_cfl_allreduce(c, &cfl_dt))
-                return rc;
-            if (int rc = fcpt_calculate_timestep(c, cfl_dt, &dt))
-                return rc;
-            if (int rc = fcpt_snap_to_monitor(c, dt, &step_dt))
-                return rc;
-            const double time_next_monitor = (k.n_monitor + 1) * c->d.monitor_timestep;
-            if (int rc = fcpt_step(c, step_dt))
-                return rc;
-            if (int rc = fcpt_exchange(c))
-                return rc;
-            if (int rc = fcpt_post(c, step_dt))
-                return rc;
-            if (int rc = read_clock(c, &k))
-                return rc;
-            if (std::fabs(time_next_monitor - k.time) < 1e-6 * dt) {
-                fcpt_clock hc = {k.time, k.last_dt, k.n_hydro_iter, k.n_monitor + 1, 0};
-                hc.n_snapshot = hc.n_monitor / (uint32_t)(c->d.nmonitor > 0 ? c->d.nmonitor : 1);
-                if (int rc = fcpt_set_clock(c, &hc))
-                    return rc;
-            }
-        }
-    } else if (!snap) {
-        // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
-        if (graph_wanted(c) && nsteps >= 8) {
-            join_side(c);
-            if (c->graph_exec && (std::memcmp(&c->graph_P, &c->P, sizeof(Dev)) != 0 || c->graph_flags != launch_flags(c)))
-                drop_graph(c); // bodies, options, pointers or lazy flags changed since the capture
-            if (!c->graph_exec) {
-                for (; n < 2; ++n) // the lazily evaluated grids settle within two steps
-                    enqueue_device_step(c);
-                if (!capture_graph(c, 2) && !capture_graph(c, 4))
-                    c->graph_failed = true;
-            }
-            if (c->graph_exec) {
-                for (; n + c->graph_cycle <= nsteps; n += c->graph_cycle)
-                    HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
-            }
-        }
-        for (; n < nsteps; ++n)
-            enqueue_device_step(c);
-        HIPCHK(hipGetLastError());
-    } else {
-        const double t_final = (double)c->d.nsnapshots * c->d.nmonitor * c->d.monitor_timestep;
-        for (; n < nsteps; ++n) {
-            DevClock k;
-            if (int rc = read_clock(c, &k))
-                return rc;
-            if (t_final > 0 && !(k.time < t_final))
-                break;
-            double cfl_dt, dt, step_dt;
-            if (int rc = fcpt_cfl(c, &cfl_dt))
-                return rc;
-            if (int rc = fcpt_calculate_timestep(c, cfl_dt, &dt))
-                return rc;
-            if (int rc = fcpt_snap_to_monitor(c, dt, &step_dt))
-                return rc;
-            const double time_next_monitor = (k.n_monitor + 1) * c->d.monitor_timestep;
-            if (int rc = fcpt_step(c, step_dt))
-                return rc;
-            if (int rc = fcpt_post(c, step_dt))
-                return rc;
-            if (int rc = read_clock(c, &k))
-                return rc;
-            const bool towrite = std::fabs(time_next_monitor - k.time) < 1e-6 * dt;
-            if (towrite) {
-                fcpt_clock hc = {k.time, k.last_dt, k.n_hydro_iter, k.n_monitor + 1, 0};
-                hc.n_snapshot = hc.n_monitor / (uint32_t)(c->d.nmonitor > 0 ? c->d.nmonitor : 1);
-                if (int rc = fcpt_set_clock(c, &hc))
-                    return rc;
-            }
-        }
-    }
-    if (done)
-        *done = n;
     return FCPT_OK;
 }
 

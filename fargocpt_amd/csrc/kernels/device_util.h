@@ -121,6 +121,14 @@ template <int CTRL> __device__ __forceinline__ double dpp_shift(double x)
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
+#elif defined(FCPT_DPP_MOV64)
+    // the read-modify-write copy as ONE 64-bit move (gfx90a+ v_mov_b64) instead of the two v_mov_b32 the compiler emits
+    double t;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(t) : "v"(x));
+    int lo = __double2loint(t), hi = __double2hiint(t);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 #else
     int lo = __double2loint(x), hi = __double2hiint(x);
     lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
