@@ -380,6 +380,11 @@ class Context:
     def clock(self, c: Clock):
         self._call("set_clock", C.byref(c))
 
+    def dt_statistics(self, reset: bool = False):
+        lo, hi = _f64(), _f64()
+        self._call("dt_statistics", C.byref(lo), C.byref(hi), _i32(1 if reset else 0))
+        return lo.value, hi.value
+
     def state(self):
         """Host copies of the evolved grids."""
         out = {"sigma": self.download(F_SIGMA), "vrad": self.download(F_VRAD),

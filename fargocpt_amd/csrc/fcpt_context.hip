@@ -631,6 +631,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     std::memset(&clk, 0, sizeof(clk));
     clk.last_dt = d->first_dt; // Interpret.cpp:86
     clk.dt = d->first_dt;
+    clk.dt_min = 1.0e300;
+    clk.dt_max = 0.0;
     if (hipMemcpy(P.clk, &clk, sizeof(clk), hipMemcpyHostToDevice) != hipSuccess) {
         set_error("hipMemcpy of the clock failed");
         fcpt_destroy(c);
@@ -743,6 +745,28 @@ int fcpt_get_clock(const fcpt_ctx *cc, fcpt_clock *out)
     out->n_hydro_iter = k.n_hydro_iter;
     out->n_monitor = k.n_monitor;
     out->n_snapshot = k.n_snapshot;
+    return FCPT_OK;
+}
+
+// hydro_dt_logger (hydro_dt_logger.h:13-34)
+int fcpt_dt_statistics(fcpt_ctx *c, double *dt_min, double *dt_max, int32_t reset)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    DevClock k;
+    if (int rc = read_clock(c, &k))
+        return rc;
+    if (dt_min)
+        *dt_min = k.dt_min;
+    if (dt_max)
+        *dt_max = k.dt_max;
+    if (reset) {
+        k.dt_min = 1.0e300;
+        k.dt_max = 0.0;
+        *c->h_clk = k;
+        HIPCHK(hipMemcpyAsync(c->P.clk, c->h_clk, sizeof(DevClock), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     return FCPT_OK;
 }
 

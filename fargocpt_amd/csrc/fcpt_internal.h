@@ -43,7 +43,19 @@ struct DevClock {
     unsigned int n_snapshot;
     unsigned int shear_error; // sticky: k_transport_fused met |dNshift| > 1 in a step launched without fallback
     unsigned int pad;
+    // hydro_dt_logger (hydro_dt_logger.h:13-34): smallest / largest step since the last fcpt_dt_statistics(reset)
+    double dt_min, dt_max;
 };
+#ifdef __HIPCC__
+// sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227) and the step-size log, by one thread per step
+__device__ __forceinline__ void clock_advance(DevClock *clk, double dt)
+{
+    clk->time += dt;
+    clk->n_hydro_iter += 1;
+    clk->dt_min = dt < clk->dt_min ? dt : clk->dt_min;
+    clk->dt_max = dt > clk->dt_max ? dt : clk->dt_max;
+}
+#endif
 
 // Per-row damping description, built on the host (damping.cpp:311-427).
 struct DampRange {

@@ -302,8 +302,7 @@ __global__ void k_clock_scale_dt(DevClock *clk, int mode, double dt, double fact
 }
 __global__ void k_clock_advance(DevClock *clk)
 {
-    clk->time += clk->dt;
-    clk->n_hydro_iter += 1;
+    clock_advance(clk, clk->dt);
 }
 __global__ void k_clock_export_cfl(const DevClock *clk, double *out)
 {

@@ -779,8 +779,7 @@ __device__ __forceinline__ void transport_theta_march_block(const Dev &P, const 
         }
     }
     if (wave == 0 && lane == 0 && advance_clock) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
-        P.clk->time += dt;
-        P.clk->n_hydro_iter += 1;
+        clock_advance(P.clk, dt);
     }
 #undef SH_PREV
 #undef SH_NEXT

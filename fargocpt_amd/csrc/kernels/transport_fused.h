@@ -68,8 +68,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
         return;
     const int r1 = r0 + rows < nr ? r0 + rows : nr;
     if (ch.advance_clock && wave == 0 && lane == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
-        W.clk->time += P.clk->dt;
-        W.clk->n_hydro_iter += 1;
+        clock_advance(W.clk, P.clk->dt);
     }
     { // the lane shift of the previous ring covers |Nshift[i] - Nshift[i-1]| <= 1 only
         bool jump = false;

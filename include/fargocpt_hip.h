@@ -309,6 +309,10 @@ int fcpt_get_option(const fcpt_ctx *ctx, const char *name, int32_t *value);
 int fcpt_get_split(const fcpt_ctx *ctx, fcpt_split *out);
 int fcpt_get_clock(const fcpt_ctx *ctx, fcpt_clock *out);
 int fcpt_set_clock(fcpt_ctx *ctx, const fcpt_clock *in);
+/* hydro_dt_logger (src/hydro_dt_logger.h:13-34: "min dt" / "max dt" of monitor/timestepLogging.dat): the smallest and
+ * largest step length since the last call with reset != 0, kept next to the device clock so that callers who let
+ * fcpt_run_steps run many steps without reading dt still get them.  Blocks. */
+int fcpt_dt_statistics(fcpt_ctx *ctx, double *dt_min, double *dt_max, int32_t reset);
 
 /* Host <-> device copies of one grid in the reference's Field layout
  * (what read2D / write2D move, src/polargrid.cpp:135-180,301-353).

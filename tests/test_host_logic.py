@@ -193,3 +193,19 @@ def test_nan_radii_of_a_coarse_exponential_grid_are_refused(product, oracle):
     for lib in (oracle, product):
         with pytest.raises(B.FcptError, match="FCPT_EINVAL"):
             driver.make_context(lib, d)
+
+
+def test_option_names_are_documented():
+    """Every kernel-selection switch of the library (FCPT_OPTION_NAMES in csrc/fcpt_internal.h) is named in the public
+    header's description of fcpt_set_option, and nothing on the launch path reads the environment."""
+    internal = open(os.path.join(ROOT, "fargocpt_amd", "csrc", "fcpt_internal.h")).read()
+    block = internal[internal.index("#define FCPT_OPTION_NAMES"):]
+    block = block[:block.index("\n\n")]
+    names = re.findall(r"X\((\w+)\)", block)
+    assert len(names) >= 15 and len(set(names)) == len(names)
+    hdr = open(os.path.join(ROOT, "include", "fargocpt_hip.h")).read()
+    doc = hdr[hdr.index("Kernel-selection switches of one context"):hdr.index("int fcpt_set_option")]
+    missing = [n for n in names if not re.search(r"\b%s\b" % n, doc)]
+    assert not missing, missing
+    for f in ("kernels/launch.h", "fcpt_step.hip", "fcpt_exchange.hip"):
+        assert "getenv" not in open(os.path.join(ROOT, "fargocpt_amd", "csrc", f)).read(), f
