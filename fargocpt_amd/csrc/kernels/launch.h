@@ -94,11 +94,10 @@ void launch_artificial_viscosity(const Dev &P, hipStream_t st)
 
 void launch_recalculate_viscosity(const Dev &P, hipStream_t st)
 {
-    // recalculate_viscosity, SourceEuler.cpp:205-223 (AspectRatioMode 0)
+    // recalculate_viscosity, SourceEuler.cpp:205-223 (AspectRatioMode 0): c_s, H (and nu when alpha) in one launch;
+    // the isothermal alpha-nu never changes after init
     if (P.adiabatic)
-        LAUNCH2D(KID_ADI_CS_H, k_adi_cs_h, P.nr, P);
-    if (P.alpha_viscosity && P.adiabatic)
-        LAUNCH2D(KID_VISCOSITY, k_viscosity, P.nr, P); // isothermal alpha-nu never changes after init
+        LAUNCH2D(KID_ADI_CS_H, k_adi_derived, P.nr, P, 0);
 }
 
 void launch_viscosity_field(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISCOSITY, k_viscosity, P.nr, P); }
@@ -246,10 +245,10 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
 void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_FUSED, k_visc_fused, P.nr + 1, P); }
 void launch_substep3_after_fused(const Dev &P, hipStream_t st)
 {
-    // SubStep3 (SourceEuler.cpp:956-1051) with Q+ already evaluated by k_visc_fused
-    LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P);
-    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr - 2, P, 1);
-    LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
+    // SubStep3 (SourceEuler.cpp:956-1051) with Q+ already evaluated by k_visc_fused, and the temperature floor /
+    // ceiling behind it, in one launch (the TEMPERATURE grid the reference refreshes here is read by nothing before
+    // recalculate_derived_disk_quantities rewrites it)
+    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr, P, 2);
 }
 
 // viscosity.cpp:256-348: the correction factors depend on nu and Sigma only
@@ -274,19 +273,15 @@ void launch_viscous_update(const Dev &P, hipStream_t st)
 void launch_substep3_cooling_only(const Dev &P, hipStream_t st)
 {
     // compute_heating_cooling_for_CFL at init (SourceEuler.cpp:1507-1547): Q+ = 0 (gas at rest), Q- / alpha
-    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr - 2, P, 0);
+    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr, P, 0);
 }
 
 void launch_substep3(const Dev &P, int update_energy, hipStream_t st)
 {
     // SubStep3, SourceEuler.cpp:956-1051 (update_energy = 1) or the Q+/Q- part of
     // compute_heating_cooling_for_CFL, :1507-1547 (update_energy = 0)
-    if (update_energy)
-        LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P);
     LAUNCH2D(KID_QPLUS, k_qplus_qminus, P.nr, P);
-    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr - 2, P, update_energy);
-    if (update_energy)
-        LAUNCH2D(KID_TRANGE, k_temperature_range, P.nr, P);
+    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr, P, update_energy ? 2 : 0);
 }
 
 // rows [7,14) and [nr-14,nr-7) -> buffers (unpack = 0), buffers -> rows [0,7) and [nr-7,nr) (unpack = 1)
@@ -568,11 +563,7 @@ void launch_derived(const Dev &P, hipStream_t st)
 {
     // recalculate_derived_disk_quantities, SourceEuler.cpp:225-249 (AspectRatioMode 0)
     if (P.adiabatic) {
-        LAUNCH2D(KID_TEMPERATURE, k_temperature, P.nr, P);
-        LAUNCH2D(KID_ADI_CS_H, k_adi_cs_h, P.nr, P);
-        LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P);
-        if (P.alpha_viscosity)
-            LAUNCH2D(KID_VISCOSITY, k_viscosity, P.nr, P);
+        LAUNCH2D(KID_ADI_CS_H, k_adi_derived, P.nr, P, 3); // T, c_s, H, P, nu
     } else {
         LAUNCH2D(KID_PRESSURE, k_pressure, P.nr, P);
     }

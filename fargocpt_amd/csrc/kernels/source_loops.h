@@ -255,6 +255,31 @@ template <bool ROWU> __global__ void k_temperature(const Dev P)
     }
 }
 
+// recalculate_derived_disk_quantities (SourceEuler.cpp:225-249) / recalculate_viscosity (:205-223) of the ideal EOS in
+// ONE launch: temperature, sound speed, scale height, pressure, viscosity are pointwise functions of Sigma and e, with
+// the expressions of k_temperature, k_adi_cs_h, k_pressure, k_viscosity.  what: bit 0 temperature, bit 1 pressure
+// (c_s, H and nu always).  Narrow grids run these between the per-loop kernels: four launches of 5 us each were a
+// fifth of their step.
+template <bool ROWU> __global__ void k_adi_derived(const Dev P, int what)
+{
+    CELL(0, P.nr);
+    const double e = P.energy[IDX(i, j)], sg = P.sigma[IDX(i, j)];
+    if (what & 1) {
+        const double c_v_inv = P.mu / P.Rgas * (P.gamma - 1.0);
+        P.temperature[IDX(i, j)] = c_v_inv * e / sg;
+    }
+    const double cs = sqrt(P.gamma * (P.gamma - 1.0) * e / sg);
+    P.soundspeed[IDX(i, j)] = cs;
+    const double r = P.Rmed[i];
+    const double inv_omega_kepler = 1.0 / sqrt(P.G * P.Mc / (r * r * r));
+    const double H = cs / (sqrt(P.gamma)) * inv_omega_kepler;
+    P.scale_height[IDX(i, j)] = H;
+    if (what & 2)
+        P.pressure[IDX(i, j)] = (P.gamma - 1.0) * e;
+    if (P.alpha_viscosity)
+        P.viscosity[IDX(i, j)] = P.alpha * H * cs;
+}
+
 // viscosity/viscosity.cpp:149-209: div v, tau_rr, tau_phiphi
 template <bool ROWU> __global__ void k_stress_diag(const Dev P)
 {
@@ -524,9 +549,15 @@ __device__ __forceinline__ Cooling cooling_terms(const Dev &P, int i, int j, int
 }
 // SourceEuler.cpp:1000-1048: energy update of SubStep3 (update_energy != 0) or only the
 // alpha rescaling of compute_heating_cooling_for_CFL (:1520-1545)
+// update_energy = 2: followed by SetTemperatureFloorCeilValues on all rings (k_temperature_range) in the same launch
 template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
 {
-    CELL(1, P.nr - 2);
+    CELL(0, P.nr);
+    if (i < 1 || i >= P.nr - 1) { // SubStep3 itself runs on rings [1, Nr-1)
+        if (update_energy == 2)
+            P.energy[IDX(i, j)] = clamp_energy(P, P.energy[IDX(i, j)], P.sigma[IDX(i, j)]);
+        return;
+    }
     const double dt = P.clk->dt;
     const double H = P.scale_height[IDX(i, j)];
     const double sigma = P.sigma[IDX(i, j)];
@@ -544,6 +575,8 @@ template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
             energy_new = sqrt(sqrt(e4)) * (P.Rgas / P.mu * sigma / (P.gamma - 1.0));
             Qminus = Qplus;
         }
+        if (update_energy == 2)
+            energy_new = clamp_energy(P, energy_new, sigma);
         P.energy[IDX(i, j)] = energy_new;
     }
     P.qplus[IDX(i, j)] = Qplus;
