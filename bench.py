@@ -269,6 +269,12 @@ def main():
         for _ in range(2):
             parity_ctx.calculate_timestep(parity_ctx.cfl())
         parity_ctx.run_steps(PARITY_STEPS)
+    settle_steps = 0
+    if multi or rehearse:
+        # no parity leg here (the oracle is a one-slab checker): the same number of steps on the timed context itself,
+        # so that N > 1 and N = 1 start their timed regions on equally settled clocks
+        settle_steps = PARITY_STEPS
+        run(settle_steps)
 
     # ---- warm-up, with a per-kernel calibration pass to find the dominant kernel --
     cal = min(3, max(1, args.warmup))
@@ -364,12 +370,15 @@ def main():
             "ms_per_step_per_rank": per_rank_ms,
             # what ran untimed on this context before the timed region, and the same K-step block timed again
             # right after it (clock ramp / settling)
-            "untimed_steps_before_timed_region": args.warmup,
+            "untimed_steps_before_timed_region": args.warmup + settle_steps,
             "untimed_other": "2 CFL + CalculateTimeStep calls of sim::init; the first min(3, W) warm-up steps carry "
                              "HIP-event pairs around every kernel (calibration of the dominant kernel)"
                              + (f"; before the warm-up, {PARITY_STEPS} steps of the same workload on a second context "
                                 "(device half of cpu_baseline's parity check), queued on the same stream"
-                                if parity_ctx is not None else ""),
+                                if parity_ctx is not None else "")
+                             + (f"; before the warm-up, {settle_steps} further steps of this workload (the N = 1 run queues "
+                                "as many on its parity context): equally settled GPU clocks"
+                                if settle_steps else ""),
             "ms_per_step_blocks": blocks,
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
