@@ -184,8 +184,9 @@ int enqueue_exchange(fcpt_ctx *c)
 // cfl.cpp:185-379 with the result left in c->d_cfl
 int enqueue_cfl_allreduce(fcpt_ctx *c)
 {
+    c->P.cfl_export = c->d_cfl; // the final fold of the reduction writes the all-reduce's operand itself
     enqueue_cfl(c, 0);
-    launch_clock_export_cfl(c->P.clk, c->d_cfl, c->stream);
+    c->P.cfl_export = nullptr;
     const int rc = comm_allreduce_min(c->comm, c->d_cfl, c->stream);
     return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
 }

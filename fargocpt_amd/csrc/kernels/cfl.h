@@ -245,6 +245,8 @@ __device__ __forceinline__ void cfl_fold(const Dev &P, const double *part, int n
         if (nparts > 0)
             dt = dmin(dt, P.cfl / sqrt(smax));
         P.clk->cfl_bits = (unsigned long long)__double_as_longlong(dt);
+        if (P.cfl_export)
+            *P.cfl_export = dt;
         if (apply_policy) { // sim::CalculateTimeStep (simulation.cpp:100-118) for single-slab device loops
             const double a = P.cfl_max_var * P.clk->last_dt;
             const double rv = dt < a ? dt : a;
