@@ -149,7 +149,7 @@ struct Options {
     int source_ring_parts;  // 0: the transport's ring mean re-reads v_phi
     int fused_damping;      // 0: the wave damping as separate kernels in the final boundary call
     int inline_potential;   // 0: ideal EOS: k_potential every step instead of the evaluation inside k_source_march_adi
-    int cfl_thermal;        // 0: ideal EOS: the CFL kernel re-reads Sigma, e, Q+, Q- instead of the transport's per-cell sum
+    int cfl_thermal;        // 1: ideal EOS: the transport stores the cell-local CFL terms, the CFL kernel reads 3 grids, not 6
     int bc_fold;            // 0: the pre-transport boundary call as its own launch instead of inside the source march
     int comm_overlap;       // fcpt_exchange: transfers on the library's communication stream under the interior CFL
     int comm_loopback;      // rehearsal on one GPU: both "neighbours" of the slab are the slab itself

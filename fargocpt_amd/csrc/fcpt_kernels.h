@@ -53,6 +53,7 @@ struct TransportResult {
     int marched;  // > 0: a marching kernel ran (new state complete, clock advanced)
     double *sigma, *energy, *vrad, *vazi;
     int split;    // only a part of the chunks was marched
+    int thermal;  // the kernel left the cell-local CFL terms of the new state in Dev::cfl_thermal
 };
 enum { TRANSPORT_ALL = 0, TRANSPORT_EDGES = 1, TRANSPORT_INTERIOR = 2 };
 TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part = TRANSPORT_ALL);

@@ -174,7 +174,7 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool spl
     // a marching transport kernel stored the cell-local CFL terms with the new Sigma and e; they stay those of the
     // final state if nothing but boundary rings and ghost rows changes before the next CFL reduction (the wave
     // damping folded into that kernel, or no damping zone on this slab)
-    c->thermal_valid = P.cfl_thermal != nullptr && tr.marched > 0 && !frog && (!c->damp_any || P.damp_in_step != 0);
+    c->thermal_valid = tr.thermal != 0 && tr.marched > 0 && !frog && (!c->damp_any || P.damp_in_step != 0);
     // the marching transport is out of place: the new state may sit in the scratch twins
     if (tr.sigma != c->P.sigma)
         std::swap(c->P.sigma, c->P.sigA);

@@ -440,7 +440,7 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     // Transport, TransportEuler.cpp:112-136
-    TransportResult res = {0, W.sigma, W.energy, W.vrad, W.vazi};
+    TransportResult res = {0, W.sigma, W.energy, W.vrad, W.vazi, 0, 0};
     // ---- everything in one kernel (tiled rings only) ------------------------------------------
     int CF = P.nphi >= 256 ? 1 : 0; // 1 cell per lane: 3 waves per SIMD (2 cells: 284 VGPRs, 1 wave)
     if (P.opt.transport_fused >= 0) { // 0: off, 1 / 2: cells per lane
@@ -481,7 +481,9 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
     else                                                                                                             \
         KLAUNCH(KID_TRANSPORT_FUSED, (KK<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, fallback, ch)
 #define TFK(CC, AA, DD)                                \
-    if (CC == 1) {                                     \
+    if (CC == 1 && AA && Wm.cfl_thermal) {             \
+        TFK2(k_transport_fused_therm, 1, true, DD);    \
+    } else if (CC == 1) {                              \
         TFK2(k_transport_fused, 1, AA, DD);            \
     } else {                                           \
         TFK2(k_transport_fused_wide, 2, AA, DD);       \
@@ -517,6 +519,7 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
             launch_fallback(P, Wm, st);
         }
         res.marched = tiles;
+        res.thermal = CF == 1 && P.adiabatic && Wm.cfl_thermal != nullptr;
         res.sigma = Wm.sigma, res.energy = Wm.energy, res.vrad = Wm.vrad, res.vazi = Wm.vazi;
         return res;
     }
@@ -547,6 +550,7 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         Wm.vrad = P.vrad == W.vrad ? W.vrad_b : W.vrad;
         Wm.vazi = P.vazi == W.vazi ? W.vazi_b : W.vazi;
         res.marched = launch_theta_march(P, Wm, C, periodic, 1, nullptr, st);
+        res.thermal = P.adiabatic && Wm.cfl_thermal != nullptr;
         res.vrad = Wm.vrad, res.vazi = Wm.vazi;
     } else {
         LAUNCH2D_T(KID_THETA1, k_transport_theta, 1, P.nr, P, inB, outA);

@@ -43,7 +43,9 @@ __device__ __forceinline__ double damp_apply(double X, int type, double ef, cons
     return (X - X0) * ef + X0;
 }
 
-template <int C, bool ADI, bool DAMP, int LIM>
+// THERM: the cell-local CFL terms of the new state are stored with it (ideal EOS; its own instantiation, because the
+// extra live values cost the kernel five dwords of scratch at 128 VGPRs)
+template <int C, bool ADI, bool DAMP, int LIM, bool THERM>
 __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W, int tiles, int rows, int has_fallback,
                                                      const TfChunks &ch)
 {
@@ -370,7 +372,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
             if (m < r1)
                 fetch(m + 2, nxt);
         }
-        if (ADI && out_on && W.cfl_thermal) { // the cell-local CFL terms of the new state (cfl_thermal_term)
+        if (ADI && THERM && out_on) { // the cell-local CFL terms of the new state (cfl_thermal_term)
             const ThermalRing tr = thermal_ring(W, i);
 #pragma unroll
             for (int c = 0; c < C; ++c)
@@ -421,11 +423,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 k_transport_fused(const Dev P, const Dev W, int tiles, int rows, int has_fallback, const TfChunks ch)
 {
     static_assert(C == 1, "the 4-wavefront kernel is the one-cell-per-lane form");
-    transport_fused_body<C, ADI, DAMP, LIM>(P, W, tiles, rows, has_fallback, ch);
+    transport_fused_body<C, ADI, DAMP, LIM, false>(P, W, tiles, rows, has_fallback, ch);
+}
+template <int C, bool ADI, bool DAMP, int LIM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_transport_fused_therm(const Dev P, const Dev W, int tiles, int rows, int has_fallback, const TfChunks ch)
+{
+    static_assert(C == 1 && ADI, "the cell-local CFL terms belong to the energy equation");
+    transport_fused_body<C, ADI, DAMP, LIM, true>(P, W, tiles, rows, has_fallback, ch);
 }
 template <int C, bool ADI, bool DAMP, int LIM>
 __global__ void __launch_bounds__(256) k_transport_fused_wide(const Dev P, const Dev W, int tiles, int rows, int has_fallback,
                                                               const TfChunks ch)
 {
-    transport_fused_body<C, ADI, DAMP, LIM>(P, W, tiles, rows, has_fallback, ch);
+    transport_fused_body<C, ADI, DAMP, LIM, false>(P, W, tiles, rows, has_fallback, ch);
 }

@@ -686,3 +686,13 @@ def test_graph_replay_is_bit_identical(product, case):
     assert out[0][1][2] == 36
     for k in out[0][0]:
         assert np.array_equal(out[0][0][k], out[1][0][k]), k
+
+
+@pytest.mark.parametrize("nslabs", [1, 2])
+def test_cfl_thermal_option(product, oracle, nslabs, monkeypatch):
+    """Option cfl_thermal (off by default: measured slower at 2048 x 4096): the marching transport stores the
+    cell-local part of the ideal-EOS CFL sum with the new state and k_cfl_rings reads it instead of Sigma, e, Q+, Q-.
+    Same dt history and fields as the oracle, on one slab and on two."""
+    monkeypatch.setenv("FCPT_CFL_THERMAL", "1")
+    d = setups.planet_disk(product, 80, 320, adiabatic=True)
+    _check(run_pair(product, oracle, d, 25, bodies=setups.jupiter_bodies(d), nslabs=(nslabs, 1)), ("sigma", "vrad", "vazi", "energy"))
