@@ -463,6 +463,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     if (!rc && d->eos == FCPT_EOS_IDEAL)
         rc = dev_alloc(c, &thermal_grid, ns);
     c->thermal_grid = thermal_grid;
+    if (!rc && d->eos == FCPT_EOS_IDEAL)
+        rc = dev_alloc(c, &P.qdiff, ns);
 #undef AL
     if (!rc && hipHostMalloc((void **)&c->h_clk, sizeof(DevClock)) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -813,8 +815,10 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
         c->thermal_valid = false;
         c->ghosts_unknown = true;
     }
-    if (f == FCPT_F_QPLUS || f == FCPT_F_QMINUS)
+    if (f == FCPT_F_QPLUS || f == FCPT_F_QMINUS) {
         c->thermal_valid = false;
+        c->qdiff_valid = false;
+    }
     if (f == FCPT_F_SCALE_HEIGHT)
         c->potential_valid = false;
     c->cfl_interior = false;

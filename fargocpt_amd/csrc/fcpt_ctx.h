@@ -58,6 +58,7 @@ struct fcpt_ctx {
     bool damp_any = false;     // this slab holds rings of a damping zone
     double *thermal_grid = nullptr; // storage of Dev::cfl_thermal (the view's pointer is null when the option is off)
     bool thermal_valid = false;     // ... and it describes the current state (set by a marching-transport step)
+    bool qdiff_valid = false;       // Dev::qdiff holds Q+ - Q- of the grids (written by the last kick's march)
     bool damp_foldable = false; // ... and its damping can be folded into the transport (no "mean" target, Euler)
     // fcpt_step_device_begin: the interior chunks of the transport run on `side` while the caller's stream
     // marches the chunks with the neighbours' ghost rings, packs and sends them

@@ -216,6 +216,8 @@ struct Dev {
     double *cfl_part; // per-block maxima of the CFL reduction
     double *cfl_thermal; // ideal EOS: invdt1^2 + invdt5^2 + invdt6^2 per cell, left by the marching transport (null: off)
     int cfl_thermal_on;  // ... and valid for the current state: k_cfl_rings reads it instead of Sigma, e, Q+, Q-
+    double *qdiff;       // ideal EOS: Q+ - Q- of the last kick, written by k_source_march_adi beside Q+ and Q-
+    int qdiff_on;        // ... and current: the CFL kernel reads it instead of the two grids
     double *cfl_export;  // non-null: the final fold also leaves the slab's CFL step here (the MIN all-reduce's operand)
     int *cfl_tickets; // 1 + CFL_TICKET_LANES counters of the "last workgroup folds" scheme (zero between launches)
     // per-ring partial sums of v_phi left by k_source_march for the transport's ring mean

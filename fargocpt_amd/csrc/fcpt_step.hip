@@ -55,6 +55,7 @@ bool enqueue_kick(fcpt_ctx *c, bool fold_bc = false)
         const int segs = c->march_source ? launch_source_march(P, st, fold_bc, &c->kick_bc_folded) : 0;
         c->src_parts = segs > 0 ? segs : 0;
         c->kick_energy_b = segs != 0 && P.adiabatic;
+        c->qdiff_valid = segs != 0 && P.adiabatic; // the march wrote Q+ - Q- beside Q+ and Q-; the loop kernels do not
         if (!segs) {
             ensure_pressure(c);
             launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
@@ -65,6 +66,7 @@ bool enqueue_kick(fcpt_ctx *c, bool fold_bc = false)
         }
         return true;
     }
+    c->qdiff_valid = false;
     ensure_pressure(c);
     launch_source(P, st);
     launch_artificial_viscosity(P, st);
@@ -228,6 +230,7 @@ void enqueue_cfl(fcpt_ctx *c, int apply_policy)
 {
     join_side(c);
     c->P.cfl_thermal_on = c->thermal_valid ? 1 : 0;
+    c->P.qdiff_on = c->qdiff_valid ? 1 : 0;
     launch_cfl(c->P, apply_policy, c->stream, c->cfl_interior);
     c->cfl_interior = false;
 }
@@ -253,6 +256,7 @@ int fcpt_cfl_begin(fcpt_ctx *c)
         return FCPT_OK;
     ProfScope prof_scope(c);
     c->P.cfl_thermal_on = c->thermal_valid ? 1 : 0;
+    c->P.qdiff_on = c->qdiff_valid ? 1 : 0;
     c->cfl_interior = launch_cfl_interior(c->P, c->stream);
     HIPCHK(hipGetLastError());
     return FCPT_OK;

@@ -156,8 +156,12 @@ template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings
                 } else if (ADI) {
                     e2 = *(const D2 *)(P.energy + row + j);
                     s2 = *(const D2 *)(P.sigma + row + j);
-                    qp = *(const D2 *)(P.qplus + row + j);
-                    qm = *(const D2 *)(P.qminus + row + j);
+                    if (P.qdiff_on) { // Q+ - Q- as one grid, left by the source march
+                        qp = *(const D2 *)(P.qdiff + row + j);
+                    } else {
+                        qp = *(const D2 *)(P.qplus + row + j);
+                        qm = *(const D2 *)(P.qminus + row + j);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {

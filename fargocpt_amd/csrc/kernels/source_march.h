@@ -627,6 +627,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                         P.energy_b[IDX(k, j)] = e;
                         P.qplus[IDX(k, j)] = qplus;
                         P.qminus[IDX(k, j)] = qminus;
+                        P.qdiff[IDX(k, j)] = qplus - qminus; // what the CFL condition needs of the two (cfl.cpp:303-316)
                         // step_LeapFrog evaluates the mid-step potential with the scale height this kick's
                         // recalculate_viscosity left behind (simulation.cpp:340-378), not with that of the
                         // transported state: keep the grid for it
