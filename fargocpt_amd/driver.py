@@ -103,15 +103,17 @@ class SlabSet:
     def gather(self):
         """Global fields with overlap rings stripped (write2D, polargrid.cpp:135-180)."""
         out = {}
-        for name, f in (("sigma", B.F_SIGMA), ("vrad", B.F_VRAD), ("vazi", B.F_VAZI),
-                        ("energy", B.F_ENERGY)):
+        grids = [("sigma", B.F_SIGMA), ("vrad", B.F_VRAD), ("vazi", B.F_VAZI), ("energy", B.F_ENERGY)]
+        if self.ctxs[0].desc.write_massflow:
+            grids.append(("massflow", B.F_MASSFLOW))
+        for name, f in grids:
             parts = []
             for c in self.ctxs:
                 a = c.download(f)
                 s = c.split
                 lo = 0 if s.is_first else B.OVERLAP
                 hi = a.shape[0] - (0 if s.is_last else B.OVERLAP)
-                if f == B.F_VRAD and not s.is_last:
+                if f in B.VECTOR_FIELDS and not s.is_last:
                     hi -= 1
                 parts.append(a[lo:hi])
             out[name] = np.concatenate(parts, axis=0)

@@ -78,6 +78,8 @@ def draw(lib, seed):
     # fused transport hands over to its fallback kernels past the shear limit)
     global _EXTRA
     _EXTRA = {"dt_scale": pick(1.0, 1.0, 1.0, 2.0, 3.5) if WIDE else 1.0}
+    if WIDE:   # WriteMassFlow: the MASSFLOW grid is compared like a state grid
+        d.write_massflow = int(rng.integers(3) == 0)
     if WIDE:   # initial-condition switches (init.cpp:255-343)
         d.initialize_pure_keplerian = int(rng.integers(4) == 0)
         d.initialize_vradial_zero = int(rng.integers(4) == 0)
@@ -139,7 +141,7 @@ def test_random_configuration(product, oracle, seed):
     d, nslabs, planet = draw(product, seed)
     bodies = setups.jupiter_bodies(d) if planet else None
     adiabatic = d.eos == B.EOS_IDEAL
-    fields = ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ())
+    fields = ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ()) + (("massflow",) if d.write_massflow else ())
 
     def attempt(nsteps):
         try:
