@@ -541,6 +541,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     P.emin_fac = d->minimum_temperature / d->mu * d->Rgas / (d->adiabatic_index - 1.0);
     P.emax_fac = d->maximum_temperature / d->mu * d->Rgas / (d->adiabatic_index - 1.0);
     P.b_fac = d->mu * (d->adiabatic_index - 1.0) / d->Rgas;
+    P.alpha_fac = 2.0 * 4.0 * d->sigma_sb / d->c_light;
     P.tmax = d->maximum_temperature;
     P.sigma_floor_abs = d->sigma_floor * d->sigma0;
     P.sigma_floor_rel = d->sigma_floor;

@@ -243,6 +243,7 @@ struct Dev {
     CArr g_omk; // Omega_K(Rmed[i])
     double emin_fac, emax_fac; // T_min|max / mu * R / (gamma - 1): energy floor / ceiling per unit Sigma
     double b_fac;              // mu (gamma - 1) / R of SubStep3's alpha
+    double alpha_fac;          // 2 * 4 sigma_SB / c of the same (one multiply per cell instead of an IEEE division)
     double alpha, nu_const, radial_viscosity_factor, art_visc_factor, heating_viscous_factor;
     double omega_frame, thickness_smoothing, cfl, cfl_max_var, heating_cooling_cfl_limit;
     double monitor_timestep;

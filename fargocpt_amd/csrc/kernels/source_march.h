@@ -462,7 +462,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
             if (r < nr - 1) { // compression_heating, rows [0, Nr-1)
                 const double DIV_V = (vr1_m * R.rinf_b1 - vr1_1 * R.rinf_b0) * R.inv_drsuprb_b +
                                      (va1n_1 - va1_1) * P.invdphi * R.inv_rmed_b;
-                e = e * exp(-gm1 * dt * DIV_V);
+                e = e * exp_small(-gm1 * dt * DIV_V);
             }
             if (AV == 1) {
                 const double eps_rr = (vr1_m - vr1_1) * R.inv_drsup_b;
@@ -472,7 +472,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                 qr_1 = l_sq * S_1 * -div_V * (eps_rr - 1.0 / 3.0 * div_V);
                 qp_1 = l_sq * S_1 * -div_V * (eps_pp - 1.0 / 3.0 * div_V);
                 if (dissipate && r > P.zero_no_ghost && r < P.max_no_ghost) {
-                    const double Qplus = -l_sq * div_V * S_1 * 1.0 / 3.0 *
+                    const double Qplus = -l_sq * div_V * S_1 * (1.0 / 3.0) * // (a multiply: the reference's `* 1.0 / 3.0` is an IEEE division per cell)
                                          (eps_rr * eps_rr + eps_pp * eps_pp + (eps_rr - eps_pp) * (eps_rr - eps_pp));
                     e += Qplus * dt;
                 }
@@ -599,7 +599,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                     }
                     if (row_va) { // SubStep3, rows [1, Nr-1)
                         const double bb = P.b_fac * fast_rcp(S_2), b2 = bb * bb; // substep3_alpha
-                        const double alpha = 1.0 + 2.0 * H_2 * 4.0 * P.sigma_sb / P.c_light * (b2 * b2) * (e * e * e);
+                        const double alpha = 1.0 + H_2 * P.alpha_fac * (b2 * b2) * (e * e * e); // alpha_fac = 2 * 4 sigma_SB / c
                         const double ralpha = fast_rcp(alpha);
                         double tau_eff = 0.0;
                         if (cooling) { // calculate_qminus
