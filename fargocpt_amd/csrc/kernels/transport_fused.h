@@ -34,9 +34,23 @@ template <int C> struct TfHalo {
     static constexpr int hi = 6;
 };
 
-// wave damping with the ring's precomputed exp(-dt f / tau) (k_ring_mean): types as damp_value
+// wave damping with the ring's precomputed exp(-dt f / tau) (k_ring_mean): types as damp_value.
+// ONE_BLOCK: the load of the reference value and its use in one basic block.  A load whose use sits behind another
+// branch leaves the compiler's s_waitcnt pass with a "maybe pending" register at every later store of the loop; the
+// ideal-EOS kernel, whose prefetch is pinned (see the bottom of its loop), needs this form, the isothermal one
+// measured 5 % slower with it (three A/B pairs) and keeps the other.
+template <bool ONE_BLOCK>
 __device__ __forceinline__ double damp_apply(double X, int type, double ef, const double *ref, int cell, double zero_target)
 {
+    if (ONE_BLOCK) {
+        if (type == 1) {
+            const double X0 = ref[cell];
+            return (X - X0) * ef + X0;
+        }
+        if (type != 0)
+            return (X - zero_target) * ef + zero_target;
+        return X;
+    }
     if (type == 0)
         return X;
     const double X0 = type == 1 ? ref[cell] : zero_target;
@@ -58,6 +72,9 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     // quantities of the rolling window instead of being carried along (ulp-level differences: e = (e / Sigma) Sigma,
     // v_phi = ((v_phi + r Omega) r) / r - r Omega)
     constexpr bool DIET = ADI;
+    // PIN: the prefetch of ring m+2 is pinned behind convert() of ring m+1 (bottom of the loop).  Ideal EOS only:
+    // -1.8 % per step there (four A/B pairs), no gain in the isothermal kernel.
+    constexpr bool PIN = ADI;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int chunk_l = wave / tiles; // chunk within this launch
@@ -170,10 +187,9 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     };
     // ring k (raw) -> newest window slot; vr_k = v_r(k) from the previous ring's fetch
     double vr_last[C];
-    auto convert = [&](int k, const RingRaw &o) {
+    // (r, romega: Rmed[k] and Rmed[k] OmegaFrame, from the caller's batch of per-ring scalars)
+    auto convert = [&](int k, const RingRaw &o, double r, double romega) {
         const bool in_k = k >= 0 && k < nr;
-        const ThetaRow tk = crow_load(P.theta_tab, in_k ? k : 0);
-        const double r = tk.rmed, romega = tk.r_omega;
         const double va_n = lane_next(o.va[0]); // v_phi of cell j+1 of the last cell of the lane
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -204,7 +220,10 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     for (int c = 0; c < C; ++c)
         vr_last[c] = nxt.vr[c]; // v_r(r0-3)
     fetch(r0 - 3, nxt);
-    convert(r0 - 3, nxt);
+    {
+        const ThetaRow t3 = crow_load(P.theta_tab, r0 - 3 >= 0 ? r0 - 3 : 0);
+        convert(r0 - 3, nxt, t3.rmed, t3.r_omega);
+    }
     fetch(r0 - 2, nxt);
     int ns_prev = 0;
 
@@ -218,6 +237,10 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
         DampRow di;
         if (DAMP)
             di = crow_load(W.damp_tab, do_i ? i : 0);
+        // ... and of ring m+1, which the bottom of this iteration turns into specific quantities
+        typedef const double __attribute__((address_space(4))) *cdptr;
+        const cdptr tn = (cdptr)(const void *)(P.theta_tab + (m + 1 >= 0 && m + 1 < nr ? m + 1 : 0));
+        double r_next = tn[6], romega_next = tn[5]; // ThetaRow::rmed, ::r_omega
         // ---- R: slopes of ring m-1, fluxes through interface k = m-1 --------------------------
         double F0[NQ][C];
         {
@@ -332,11 +355,11 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                     double e = ADI ? clamp_energy_fast(P, E[c], sf) : 0.0;
                     const int g = row + jout[c];
                     if (DAMP) {
-                        vr = damp_apply(vr, di.tvr, si.ev, W.vrad0, g, 0.0);
-                        va = damp_apply(va, di.tva, si.es, W.vazi0, g, 0.0);
-                        sf = damp_apply(sf, di.tsg, si.es, W.sigma0, g, W.sigma_floor_abs);
+                        vr = damp_apply<ADI>(vr, di.tvr, si.ev, W.vrad0, g, 0.0);
+                        va = damp_apply<ADI>(va, di.tva, si.es, W.vazi0, g, 0.0);
+                        sf = damp_apply<ADI>(sf, di.tsg, si.es, W.sigma0, g, W.sigma_floor_abs);
                         if (ADI)
-                            e = damp_apply(e, di.ten, si.es, W.energy0, g, 0.0);
+                            e = damp_apply<ADI>(e, di.ten, si.es, W.energy0, g, 0.0);
                     }
                     o_vr[c] = vr, o_va[c] = va, o_s[c] = sf, o_e[c] = e;
                     out_g[c] = g;
@@ -368,7 +391,21 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
         if (DIET)
             idr_prev = rk.idr_up;
         if (m < r1 + 1) {
-            convert(m + 1, nxt);
+            convert(m + 1, nxt, r_next, romega_next);
+            // The loads of fetch() must go straight into the registers convert() has just read.  Left alone, the
+            // compiler sinks convert() below them, loads into fresh registers and copies those back behind an
+            // s_waitcnt vmcnt(0): the prefetch becomes a blocking load, once per ring.  The empty asm pins the
+            // results of convert() above it and (memory clobber) the loads below it.
+            if (PIN) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        asm volatile("" : "+v"(w[0][q][c]));
+                    asm volatile("" : "+v"(vr_last[c]));
+                }
+                asm volatile("" ::: "memory");
+            }
             if (m < r1)
                 fetch(m + 2, nxt);
         }
@@ -406,7 +443,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                         double v = P.vrad[nr * nphi + jin[c]];
                         if (DAMP) {
                             const DampRow dn = crow_load(W.damp_tab, nr);
-                            v = damp_apply(v, dn.tvr, si.ev_top, W.vrad0, nr * nphi + jin[c], 0.0);
+                            v = damp_apply<ADI>(v, dn.tvr, si.ev_top, W.vrad0, nr * nphi + jin[c], 0.0);
                         }
                         W.vrad[nr * nphi + jin[c]] = v;
                     }
