@@ -23,7 +23,9 @@ template <int OP> __device__ __forceinline__ void step(double (&x)[NCH], int (&y
         if (OP == 9) x[k] = x[k] + c;
     }
 }
-template <int OP> __global__ void __launch_bounds__(256) k_rate(const double *in, double *out, int iters)
+// clk[0..1]: shader-clock (s_memtime) and 100 MHz wall-clock (s_memrealtime) ticks wavefront 0 spent in the loop: the
+// quotient is the frequency the SIMDs actually ran at under this instruction mix
+template <int OP> __global__ void __launch_bounds__(256) k_rate(const double *in, double *out, int iters, long long *clk)
 {
     double x[NCH];
     int y[2 * NCH];
@@ -34,11 +36,17 @@ template <int OP> __global__ void __launch_bounds__(256) k_rate(const double *in
         y[2 * k] = threadIdx.x + k;
         y[2 * k + 1] = threadIdx.x * 3 + k;
     }
+    const long long c0 = clock64(), w0 = wall_clock64();
     for (int i = 0; i < iters; ++i) {
         step<OP>(x, y, c);
         step<OP>(x, y, c);
         step<OP>(x, y, c);
         step<OP>(x, y, c);
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = c1 - c0;
+        clk[1] = w1 - w0;
     }
     double s = 0;
 #pragma unroll
@@ -48,19 +56,29 @@ template <int OP> __global__ void __launch_bounds__(256) k_rate(const double *in
 }
 template <int OP> void run(const char *name, int instr_per_step, const double *din, double *dout, double ghz)
 {
-    const int blocks = 256 * 4, iters = 2000; // 4 wavefronts per SIMD on 256 CUs
+    const int blocks = 256 * 4, iters = 40000; // 4 wavefronts per SIMD on 256 CUs; ~10 ms per launch
+    static long long *dclk = nullptr;
+    if (!dclk)
+        hipMalloc(&dclk, 2 * sizeof(long long));
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    k_rate<OP><<<blocks, 256>>>(din, dout, 10);
+    for (int w = 0; w < 5; ++w) // the clocks settle over tens of milliseconds
+        k_rate<OP><<<blocks, 256>>>(din, dout, iters, nullptr);
     hipEventRecord(a);
-    k_rate<OP><<<blocks, 256>>>(din, dout, iters);
+    k_rate<OP><<<blocks, 256>>>(din, dout, iters, dclk);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
     hipEventElapsedTime(&ms, a, b);
+    long long clk[2];
+    hipMemcpy(clk, dclk, sizeof(clk), hipMemcpyDeviceToHost);
     const double wave_instr_per_simd = 4.0 /*waves*/ * iters * 4.0 * instr_per_step;
-    printf("%-34s %8.3f ms  -> %6.2f cycles per wavefront instruction at %.2f GHz\n", name, ms, ms * 1e-3 * ghz * 1e9 / wave_instr_per_simd, ghz);
+    const double f_ghz = (double)clk[0] / ((double)clk[1] * 10.0); // ticks per 10 ns
+    (void)ghz;
+    // (the launch is one round of 4 wavefronts per SIMD: launch time x measured frequency / instructions per SIMD)
+    printf("%-34s %8.3f ms  shader clock %5.3f GHz (s_memtime / s_memrealtime)  -> %6.2f cycles per wavefront instruction\n", name, ms,
+           f_ghz, ms * 1e-3 * f_ghz * 1e9 / wave_instr_per_simd);
 }
 int main()
 {
