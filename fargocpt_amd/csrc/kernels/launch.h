@@ -114,8 +114,8 @@ void launch_source_fused(const Dev &P, hipStream_t st)
 }
 // Rings per marching chunk.  A marching wavefront is a serial chain of (rows + pre-roll) ring iterations; the GPU
 // holds 256 CUs x 4 SIMDs x 4 wavefronts of these kernels at a time.  On grids that fill it several times over the
-// measured optimum is the default (24 rings at 2048 x 4096: the pre-roll of 4-5 rings per chunk against the tail of
-// the last blocks).  Smaller grids have fewer wavefronts than the GPU has slots: there the chain length is the
+// measured optimum is the default (20 rings of the transport, 24 of the source step at 2048 x 4096: the pre-roll of
+// 4-5 rings per chunk against the tail of the last blocks).  Smaller grids have fewer wavefronts than the GPU has slots: there the chain length is the
 // kernel time, so the chunks shrink until the wavefronts fill the slots once (1024 x 3072: 14-15 rings, 128 x 384: 4).
 // (measured, profiles/r02_sweep_rows_mid.txt: isothermal grids are fastest with the wavefronts filling the slots
 //  once, the ideal-EOS kernels -- 4 wavefronts per SIMD, more loads per ring -- with about 1.8 rounds: 1024 x 3072
