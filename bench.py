@@ -79,6 +79,9 @@ def parse_args():
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="one GPU: a middle slab that sends its ghost rings to itself through a 1-rank RCCL "
                          "communicator (what the exchange + MIN all-reduce add to a step; not a headline number)")
+    ap.add_argument("--rehearse-slab", default="1:3", metavar="R:N",
+                    help="with --rehearse-exchange: which slab of how many (the weak-scaling geometry of N GPUs; an inner "
+                         "or outer slab talks to itself on its one neighbour side only)")
     ap.add_argument("--settle-blocks", type=int, default=4,
                     help="after the timed region: this many more blocks of --steps steps, timed one by one "
                          "(reported as ms_per_step_blocks: shows a clock ramp over a short timed region)")
@@ -183,14 +186,15 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # kernels and RCCL off the null stream
 
     lib = fargocpt_amd.load()
-    nslabs = 3 if rehearse else world
+    reh_rank, reh_n = (int(x) for x in args.rehearse_slab.split(":"))
+    nslabs = reh_n if rehearse else world
     nr_global = args.nr * nslabs
     d = setups.planet_disk(lib, nr_global, args.nphi, adiabatic=args.eos == "ideal")
     if nslabs > 1:
         # weak scaling: keep dr/r of the 1-GPU grid, extend the disk outward
         d.rmax = d.rmin * (2.5 / 0.4) ** nslabs
         d.damping_time_radius_outer = d.rmax
-    d.rank, d.nranks = (1, 3) if rehearse else (rank, world)
+    d.rank, d.nranks = (reh_rank, reh_n) if rehearse else (rank, world)
     bodies = setups.jupiter_bodies(d)
 
     radii = lib.radii(d)
@@ -357,7 +361,7 @@ def main():
                                    "reflecting BC + damping, FARGO transport, Euler), "
                                    f"{args.nr} rings per GPU",
                        "grid": [args.nr * world, args.nphi], "parallelism": f"radial slabs x{world}",
-                       "finite": bool(finite), "rehearsal": bool(rehearse),
+                       "finite": bool(finite), "rehearsal": (f"slab {reh_rank} of {reh_n}" if rehearse else False),
                        # N > 1: after the last step every slab's ghost rings equal its neighbours' rows [7,14) /
                        # [nr-14,nr-7) bit for bit, and all slabs hold the same clock (the MIN-reduced dt)
                        "ghost_rings_and_clock_consistent": exchange_ok,
