@@ -90,16 +90,18 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     if (ch.advance_clock && wave == 0 && lane == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
         clock_advance(W.clk, P.clk->dt);
     }
-    { // the lane shift of the previous ring covers |Nshift[i] - Nshift[i-1]| <= 1 only
+    { // the lane shift of the previous ring covers |Nshift[i] - Nshift[i-1]| <= 1 only: one ring per lane (the ring by
+      // ring form was a chain of rows dependent scalar loads, 2 us at the start of every wavefront)
         bool jump = false;
-        int prev = P.nshift_c[r0 > 0 ? r0 - 1 : 0] % nphi;
-        for (int i = r0; i < r1; ++i) {
-            const int cur = P.nshift_c[i] % nphi;
+        for (int base = r0; base < r1; base += 63) { // lane 0 holds the ring below the 63 this pass tests
+            const int i = base - 1 + lane;
+            const int ic = i < 0 ? 0 : (i > r1 - 1 ? r1 - 1 : i);
+            const int cur = P.nshift_c[ic] % nphi;
+            const int prev = __builtin_amdgcn_update_dpp(cur, cur, 0x138, 0xf, 0xf, false); // wave_shr:1
             int dd = cur - prev;
             dd = dd < 0 ? -dd : dd;
             dd = dd > nphi / 2 ? nphi - dd : dd;
-            jump = jump || dd > 1;
-            prev = cur;
+            jump = jump || __builtin_amdgcn_ballot_w64(lane >= 1 && i < r1 && dd > 1) != 0;
         }
         if (jump) {
             if (lane == 0) {
