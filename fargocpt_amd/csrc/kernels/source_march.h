@@ -354,6 +354,10 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
     double vr2_1 = 0, vr2_2 = 0, va2_1 = 0, va2_2 = 0;                      // after artificial viscosity
     double trr_2 = 0, trr_3 = 0, tpp_2 = 0, tpp_3 = 0, trp_1 = 0, trp_2 = 0;
     double nsrp_1 = 0, nsrp_2 = 0, nu_3 = 0; // STAB: nu Sigma at the corners of rings m-1, m-2; viscosity of ring m-3
+    // 1 / (Sigma + Sigma(i-1)) and 1 / (Sigma + Sigma(j-1)) of a ring serve stages A, C and E of three consecutive
+    // iterations: formed once and carried (a v_rcp_f64 with its two Newton steps costs eight FMAs; four of the 28 per
+    // ring saved, -1.4 % per step).  1 / Sigma (potential, V0, SubStep3) does not fit the 128 registers as well.
+    double rr_m = 0, rr_1 = 0, rp_m = 0, rp_1 = 0;
 
     // k_potential in registers: this lane's column (cos phi_j, sin phi_j) against the bodies
     const double gg1 = P.gamma * gm1;
@@ -402,8 +406,12 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
         const SrcRow R = crow_load(P.src_tab, m + 2); // every per-ring factor of this iteration, one batch
         // ---- shift the window, take the prefetched ring m, prefetch ring m+1 ------------
-        S_3 = S_2; S_2 = S_1; S_1 = S_m;
+        if (STAB)
+            S_3 = S_2;
+        S_2 = S_1; S_1 = S_m;
         const double Sp_2 = PREV(S_2), Sp_1 = PREV(S_1);
+        const double rr_2 = rr_1, rp_2 = rp_1;
+        rr_1 = rr_m; rp_1 = rp_m;
         F_1 = F_m; e0_1 = e0_m;
         va0_1 = va0_m;
         vr1_1 = vr1_m; va1_1 = va1_m;
@@ -426,6 +434,8 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
             F_m = potential_of(crow(m), S_m, e0_m);
         const double Pr_m = gm1 * e0_m, Pr_1 = gm1 * e0_1;
         Sp_m = PREV(S_m);
+        rr_m = fast_rcp(S_m + S_1);
+        rp_m = fast_rcp(S_m + Sp_m);
         va0n_m = NEXT(va0_m);
         const double va0n_1 = NEXT(va0_1);
         const double Fp_m = PREV(F_m);
@@ -436,7 +446,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
             const int r = m;
             vr1_m = vr0_m;
             if (r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr) {
-                double gradp = 2.0 * fast_rcp(S_m + S_1);
+                double gradp = 2.0 * rr_m;
                 gradp *= (Pr_m - Pr_1);
                 gradp *= R.idr_m;
                 const double gradphi = (F_m - F_1) * R.idr_m;
@@ -448,7 +458,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
             va1_m = va0_m;
             if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
                 const double invdxtheta = R.inv_dxt_m; // 2 / (dphi (Rsup + Rinf))
-                const double gradp = 2.0 * fast_rcp(S_m + Sp_m) * (Pr_m - Prp_m) * invdxtheta;
+                const double gradp = 2.0 * rp_m * (Pr_m - Prp_m) * invdxtheta;
                 const double gradphi = (F_m - Fp_m) * invdxtheta;
                 va1_m = va0_m + dt * (-gradp - gradphi);
             }
@@ -503,21 +513,20 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
             if (AV == 1) {
                 const double qpp_p = PREV(qp_1);
                 if (r >= 1 && r < nr - 1) {
-                    const double sigma_phi_avg = 0.5 * (S_1 + Sp_1);
-                    va2_1 = va1_1 + 2.0 * dt * (R.inv_rsum_c * fast_rcp(sigma_phi_avg)) * (qp_1 - qpp_p) * P.invdphi;
+                    // 1 / sigma_phi_avg = 1 / (0.5 (S_1 + Sp_1)) = 2 rp_1, bit for bit
+                    va2_1 = va1_1 + 2.0 * dt * (R.inv_rsum_c * (2.0 * rp_1)) * (qp_1 - qpp_p) * P.invdphi;
                 }
                 if (upd_vr) {
-                    const double sigma_r_avg = 0.5 * (S_1 + S_2);
                     const double rm = R.rmed_c, rmm = R.rmed_cm1;
-                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt * fast_rcp(sigma_r_avg) * 2.0 * R.inv_drmed2_c *
+                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt * (2.0 * rr_1) * 2.0 * R.inv_drmed2_c *
                                         ((qr_1 * rm - qr_2 * rmm) - 0.5 * (qp_1 + qp_2) * (rm - rmm));
                 }
             } else if (AV == 2) {
                 const double qphi_p = PREV(qp_1);
                 if (upd_vr)
-                    vr2_1 = vr1_1 - dt * 2.0 * fast_rcp(S_1 + S_2) * (qr_1 - qr_2) * R.idr_c;
+                    vr2_1 = vr1_1 - dt * 2.0 * rr_1 * (qr_1 - qr_2) * R.idr_c;
                 if (r >= P.zero_no_ghost && r < P.max_no_ghost)
-                    va2_1 = va1_1 - dt * 2.0 * fast_rcp(S_1 + Sp_1) * (qp_1 - qphi_p) * R.inv_dxtheta_b;
+                    va2_1 = va1_1 - dt * 2.0 * rp_1 * (qp_1 - qphi_p) * R.inv_dxtheta_b;
             }
         }
         // ---- D: stress tensor: diagonal on ring m-2, r-phi on ring m-1 --------------------
@@ -575,15 +584,13 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                     }
                 }
                 if (row_va) {
-                    const double sigma_avg = 0.5 * (S_2 + Sp_2);
-                    const double dVp = dt * R.inv_rmed_k * fast_rcp(sigma_avg) *
+                    const double dVp = dt * R.inv_rmed_k * (2.0 * rp_2) *
                                        (R.two_inv_dra2_k * (R.ra1sq_k * trp_1 - R.ra0sq_k * trp_2) +
                                         (tpp_2 - tpp_p) * P.invdphi);
                     va3 = va2_2 + (STAB ? dVp * corr_phi : dVp);
                 }
                 if (k >= P.one_no_ghost_vr && k < P.maxmo_no_ghost_vr) {
-                    const double sigma_avg = 0.5 * (S_2 + S_3);
-                    const double dVr = dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
+                    const double dVr = dt * (2.0 * rr_2) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
                                        ((R.rmed_k * trr_2 - R.rmed_km1 * trr_3) * R.idr_k +
                                         (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
                     vr3 = vr2_2 + (STAB ? dVr * corr_r : dVr);

@@ -167,7 +167,9 @@ def test_hot_kernel_occupancy_budget():
         "23k_transport_fused_thermILi1ELb1ELb1ELi0E": (4, 32),
         "14k_source_marchILi1ELb0E": (6, 0),              # isothermal source step, TW artificial viscosity
         "14k_source_marchILi1ELb1E": (4, 0),              # ... with StabilizeViscosity
-        "18k_source_march_adiILi1ELb1E": (4, 0),          # ideal EOS, potential in the kernel, no cooling terms
+        # ideal EOS, potential in the kernel, no cooling terms: one loop-invariant pair lives in scratch since the pair
+        # reciprocals are carried through the window (measured: -1.4 % per step with it)
+        "18k_source_march_adiILi1ELb1E": (4, 16),
         "k_cfl_ringsILb0ELi8E": (6, 0),                   # Nphi <= 4096
         "k_cfl_ringsILb0ELi16E": (4, 0),                  # rings of up to 8192 cells
     }
