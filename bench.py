@@ -35,6 +35,8 @@ NR_PER_GPU, NPHI = 2048, 4096
 # steps of the bench workload that the oracle repeats on the CPU (120: 20-25 s on 16 host threads; on the GPU ~47 ms
 # queued ahead of the warm-up -- the clocks of a GPU that starts cold settle over ~50 ms, see ms_per_step_blocks)
 PARITY_STEPS = int(os.environ.get("FCPT_BENCH_PARITY_STEPS", "120"))
+SETTLE_STEPS = int(os.environ.get("FCPT_BENCH_SETTLE_STEPS", "150"))  # untimed, ahead of the warm-up (clock ramp)
+PROFILE_STRIDE = 4  # timed region: every 4th launch of the dominant kernel carries the HIP-event pair
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # FP64 vector issue: 256 CUs x 4 SIMDs, one wave instruction per 4 cycles per SIMD for FP64 FMA/MUL/ADD
 # (78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz), MI355X_MICROARCH.md
@@ -273,12 +275,15 @@ def main():
         for _ in range(2):
             parity_ctx.calculate_timestep(parity_ctx.cfl())
         parity_ctx.run_steps(PARITY_STEPS)
-    settle_steps = 0
+    # The GPU's clocks settle over ~100 ms of load (ms_per_step_blocks of a 20-step run: 0.382 timed, 0.375, 0.371, 0.372
+    # after it with the parity leg alone ahead of it): SETTLE_STEPS further steps of this workload on the timed context,
+    # so that a short timed region measures the settled rate.
+    settle_steps = SETTLE_STEPS
     if multi or rehearse:
         # no parity leg here (the oracle is a one-slab checker): the same number of steps on the timed context itself,
         # so that N > 1 and N = 1 start their timed regions on equally settled clocks
-        settle_steps = PARITY_STEPS
-        run(settle_steps)
+        settle_steps += PARITY_STEPS
+    run(settle_steps)
 
     # ---- warm-up, with a per-kernel calibration pass to find the dominant kernel --
     cal = min(3, max(1, args.warmup))
@@ -291,6 +296,10 @@ def main():
         run(args.warmup - cal)
 
     # ---- timed region ---------------------------------------------------------
+    # HIP events around the dominant kernel, live in the timed region (roofline.kernel_ms): an event pair costs ~3 us of
+    # stream time, 1.6 % of a step if every launch carries one -- every PROFILE_STRIDE-th launch does
+    stride = PROFILE_STRIDE if args.steps >= 4 * PROFILE_STRIDE else 1
+    ctx.set_option("profile_stride", stride)
     ctx.profile_start([names.index(dominant)], max_launches=args.steps + 8)
     if multi:
         dist.barrier()
@@ -302,6 +311,7 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     dom = ctx.profile_stop()[dominant]
+    ctx.set_option("profile_stride", 1)
     elapsed_rank = t1 - t0
     elapsed = elapsed_rank
     per_rank_ms = [1e3 * elapsed_rank / args.steps]
@@ -380,13 +390,13 @@ def main():
                              + (f"; before the warm-up, {PARITY_STEPS} steps of the same workload on a second context "
                                 "(device half of cpu_baseline's parity check), queued on the same stream"
                                 if parity_ctx is not None else "")
-                             + (f"; before the warm-up, {settle_steps} further steps of this workload (the N = 1 run queues "
-                                "as many on its parity context): equally settled GPU clocks"
+                             + (f"; before the warm-up, {settle_steps} further steps of this workload on the timed context "
+                                "(settled GPU clocks; N > 1 adds the parity leg's share, which it does not run)"
                                 if settle_steps else ""),
             "ms_per_step_blocks": blocks,
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": dom_ms, "launches": dom[1],
+                         "kernel_ms": dom_ms, "launches": dom[1], "launches_timed_every": stride,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_passes": model[0] if model else "own traffic",
                          # the whole step against SURVEY.md 8(d)'s 256|320 B per cell-update

@@ -67,6 +67,7 @@ void options_from_environment(Options &o)
     o.comm_overlap = 0;
     o.comm_loopback = 0;
     o.graph_steps = -1;
+    o.profile_stride = 1;
 #define X(n)                                                           \
     {                                                                  \
         char env[64] = "FCPT_";                                        \
@@ -1018,6 +1019,8 @@ int fcpt_profile_start(fcpt_ctx *c, uint64_t mask, int32_t max_launches)
     p.mask = mask;
     p.used = 0;
     p.open_id = -1;
+    p.stride = c->P.opt.profile_stride > 1 ? c->P.opt.profile_stride : 1;
+    p.seen = 0;
     p.ids.clear();
     c->profiling = true;
     return FCPT_OK;

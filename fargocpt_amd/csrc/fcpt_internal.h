@@ -154,11 +154,12 @@ struct Options {
     int comm_overlap;       // fcpt_exchange: transfers on the library's communication stream under the interior CFL
     int comm_loopback;      // rehearsal on one GPU: both "neighbours" of the slab are the slab itself
     int graph_steps;        // fcpt_run_steps: replay a captured hipGraph of one step (launch-bound narrow grids)
+    int profile_stride;     // fcpt_profile_start: every n-th launch of the selected kernels is timed (an event pair costs ~3 us of stream time)
 };
 #define FCPT_OPTION_NAMES                                                                                        \
     X(transport_fused) X(transport_rows) X(source_rows) X(theta_rows) X(transport_fallback) X(transport_split)    \
     X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_split)   \
-    X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(comm_overlap) X(comm_loopback) X(graph_steps)
+    X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(comm_overlap) X(comm_loopback) X(graph_steps) X(profile_stride)
 
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.
 struct Dev {

@@ -26,6 +26,7 @@ struct Profiler {
     std::vector<int> ids;
     int used = 0;
     int open_id = -1;
+    int stride = 1, seen = 0; // every stride-th launch of the selected kernels carries the event pair (option profile_stride)
     void begin(int id, hipStream_t st);
     void end(int id, hipStream_t st);
 };

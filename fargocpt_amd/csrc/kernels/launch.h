@@ -18,6 +18,8 @@ void Profiler::begin(int id, hipStream_t st)
 {
     if (!((mask >> id) & 1ull) || used + 2 > (int)events.size())
         return;
+    if (stride > 1 && (seen++ % stride) != 0)
+        return;
     (void)hipEventRecord(events[used], st);
     open_id = id;
 }

@@ -301,7 +301,7 @@ int fcpt_synchronize(fcpt_ctx *ctx);
  * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows,
  * source_rows, theta_rows, transport_fallback, transport_split, fused_source, march_source, march_source_adi,
  * theta_march, theta_fused, cfl_rings, cfl_split, source_ring_parts, fused_damping, inline_potential, cfl_thermal, bc_fold, comm_overlap,
- * comm_loopback, graph_steps.
+ * comm_loopback, graph_steps, profile_stride (fcpt_profile_start times every n-th launch of the selected kernels).
  * FCPT_EINVAL for an unknown name.  (The reference has no counterpart: its variants are compile-time.) */
 int fcpt_set_option(fcpt_ctx *ctx, const char *name, int32_t value);
 int fcpt_get_option(const fcpt_ctx *ctx, const char *name, int32_t *value);
