@@ -8,6 +8,7 @@
 // One translation unit; the kernels live in kernels/*.h by topic (included below, in this order).
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdlib>
 
 #include "fcpt_kernels.h"

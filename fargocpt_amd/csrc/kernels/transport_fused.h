@@ -243,7 +243,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
         // ... and of ring m+1, which the bottom of this iteration turns into specific quantities
         typedef const double __attribute__((address_space(4))) *cdptr;
         const cdptr tn = (cdptr)(const void *)(P.theta_tab + (m + 1 >= 0 && m + 1 < nr ? m + 1 : 0));
-        double r_next = tn[6], romega_next = tn[5]; // ThetaRow::rmed, ::r_omega
+        const double r_next = tn[offsetof(ThetaRow, rmed) / sizeof(double)], romega_next = tn[offsetof(ThetaRow, r_omega) / sizeof(double)];
         // ---- R: slopes of ring m-1, fluxes through interface k = m-1 --------------------------
         double F0[NQ][C];
         {
