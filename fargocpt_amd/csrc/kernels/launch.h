@@ -476,7 +476,8 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         else if (part == TRANSPORT_INTERIOR)
             ch = TfChunks{c_lo - lead, 0, lead, 0};
         res.split = part != TRANSPORT_ALL;
-        const dim3 grid((ch.count * tiles + 3) / 4), block(256);
+        // (8 XCDs x the wavefronts of ceil(count / 8) chunks, four to a workgroup: see the chunk mapping in the kernel)
+        const dim3 grid(ch.count >= TF_XCD_CHUNKS ? 8 * ((((ch.count + 7) / 8) * tiles + 3) / 4) : (ch.count * tiles + 3) / 4), block(256);
 #define TFK2(KK, CC, AA, DD)                                                                                        \
     if (P.limiter == FCPT_LIMITER_MC)                                                                                \
         KLAUNCH(KID_TRANSPORT_FUSED, (KK<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback, ch); \

@@ -27,6 +27,7 @@
 // The chunks of one launch: `count` of them, the first `lead` are chunks 0..lead-1 of the grid, the others follow
 // `skip` chunks further up.  All chunks at once: {n, n, 0, 1}.  Slabs with neighbours march the chunks that hold
 // the rings the neighbours are waiting for first (fcpt_step_device_begin): {1 + tail, 1, gap, 1} then {gap, 0, 1, 0}.
+#define TF_XCD_CHUNKS 16 /* launches of at least this many chunks deal whole chunks to the XCDs */
 struct TfChunks {
     int count, lead, skip, advance_clock;
 };
@@ -77,11 +78,27 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     // -1.8 % per step there (four A/B pairs), no gain in the isothermal kernel.
     constexpr bool PIN = ADI;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int chunk_l = wave / tiles; // chunk within this launch
+    // Chunks are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8; all tiles of a chunk on one XCD, whose
+    // L2 then serves their shared halo columns), in an order that starts at both ends of the slab and works inward:
+    // the rings of the damping zones cost ~1.5x (three more loads per cell, waited for on the spot), and with the
+    // chunks in radial order on contiguous XCD ranges the outer zone's wavefronts started last, on one XCD, and ran
+    // on alone (2.98 of 4 wavefronts per SIMD on average; -5.5 % kernel time, -3 % / -4.6 % per step, three A/B pairs).
+    // (launches of fewer than TF_XCD_CHUNKS chunks -- short slabs -- deal workgroups instead: every XCD gets work)
+    int chunk_l, wave;
+    if (ch.count >= TF_XCD_CHUNKS) {
+        const int xcd = blockIdx.x & 7, wq = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const int zq = __builtin_amdgcn_readfirstlane(wq / tiles);
+        chunk_l = xcd + 8 * zq; // chunk within this launch
+        wave = __builtin_amdgcn_readfirstlane(chunk_l * tiles + (wq - zq * tiles));
+    } else {
+        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        chunk_l = wave / tiles;
+    }
     if (chunk_l >= ch.count)
         return;
-    const int chunk = chunk_l < ch.lead ? chunk_l : chunk_l + ch.skip;
+    int chunk = chunk_l < ch.lead ? chunk_l : chunk_l + ch.skip;
+    if (ch.lead == ch.count && ch.skip == 0) // all chunks in one launch: 0, n-1, 1, n-2, ...
+        chunk = (chunk_l & 1) ? ch.count - 1 - (chunk_l >> 1) : (chunk_l >> 1);
     const int r0 = chunk * rows;
     const int nr = P.nr, nphi = P.nphi;
     if (r0 >= nr)
