@@ -122,6 +122,19 @@ void launch_source_fused(const Dev &P, hipStream_t st)
 // (measured, profiles/r02_sweep_rows_mid.txt: isothermal grids are fastest with the wavefronts filling the slots
 //  once, the ideal-EOS kernels -- 4 wavefronts per SIMD, more loads per ring -- with about 1.8 rounds: 1024 x 3072
 //  0.305 ms per step with 14-15 rings per chunk, 0.283 with 6-10)
+// compute units of the current device (one device per process)
+static int device_cus()
+{
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0, v = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 64;
+        n_cu = v;
+    }
+    return n_cu;
+}
 static int march_rows(int nrows, int tiles, int rows_max, int preroll, bool adiabatic)
 {
     const double slots = adiabatic ? 7400.0 : 4096.0;
@@ -141,7 +154,31 @@ static int source_rows(const Dev &P)
 {
     if (P.opt.source_rows > 0)
         return P.opt.source_rows;
-    int r = march_rows(P.nr + 1, (P.nphi + MARCH_VALID - 1) / MARCH_VALID, 24, 4, P.adiabatic != 0);
+    const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
+    int r = march_rows(P.nr + 1, segs, 24, 4, P.adiabatic != 0);
+    // Grids whose wavefronts do not fit the GPU at once (at 24 rings per chunk): the source march costs the same in
+    // every chunk, so what counts is the number of ROUNDS of resident wavefronts, an integer, times the length of a
+    // chunk with its pre-roll.  Wavefronts per SIMD of the instantiation that will run: 6 (isothermal), 4 (with
+    // StabilizeViscosity; ideal EOS), 2 (ideal EOS with cooling terms or StabilizeViscosity).  Measured (round 2,
+    // 2048 rings): ideal EOS at Nphi = 4096 best with 36 (the first length that fits one round: 0.5277 against 0.5415
+    // ms per step at 24, 0.575 at 35), at 6144 with 54 (one round; 0.774 against 0.789); isothermal at 6144 with 36
+    // (0.5104-0.5148 against 0.5303-0.5322), at 4096 with 24 (23, two rounds: 0.397 against 0.368).
+    {
+        const bool wide_adi = P.adiabatic && (P.stabilize || P.cooling_surface || P.cooling_beta || P.heating_star);
+        const int occ = P.adiabatic ? (wide_adi ? 2 : 4) : (P.stabilize ? 4 : 6);
+        const long slots = (long)device_cus() * 4 * occ;
+        auto waves = [&](int rows) { return (long)segs * ((P.nr + 1 + rows - 1) / rows); };
+        if (waves(24) > slots) {
+            long best_cost = 0;
+            for (int rows = 12; rows <= 64; ++rows) {
+                const long cost = (rows + 4) * ((waves(rows) + slots - 1) / slots);
+                if (best_cost == 0 || cost < best_cost) {
+                    best_cost = cost;
+                    r = rows;
+                }
+            }
+        }
+    }
     // the boundary call folded into the kick needs the last chunk to hold rows nr-2 .. nr: a slightly longer chunk if
     // the division leaves fewer than three rows over
     for (int dr = 0; dr < 4; ++dr) {
@@ -388,14 +425,7 @@ static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, 
 // k_transport_fallback: radial sweep, grid barrier, azimuthal march behind one idle check
 static void launch_fallback(const Dev &P, const Dev &Wm, hipStream_t st)
 {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0, v = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 64;
-        n_cu = v;
-    }
+    const int n_cu = device_cus();
     ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     const Launch2D l = launch2d((P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS, P.nphi);
     const int gx = (int)l.grid.x, gy = (int)l.grid.y;
