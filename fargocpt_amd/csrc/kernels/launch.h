@@ -114,14 +114,17 @@ void launch_source_fused(const Dev &P, hipStream_t st)
     LAUNCH2D(KID_SRC_FUSED, k_src_fused, P.nr + 1, P);
     LAUNCH2D(KID_AV_FUSED, k_av_fused, P.nr + 1, P);
 }
-// Rings per marching chunk.  A marching wavefront is a serial chain of (rows + pre-roll) ring iterations; the GPU
-// holds 256 CUs x 4 SIMDs x 4 wavefronts of these kernels at a time.  On grids that fill it several times over the
-// measured optimum is the default (20 rings of the transport, 24 of the source step at 2048 x 4096: the pre-roll of
-// 4-5 rings per chunk against the tail of the last blocks).  Smaller grids have fewer wavefronts than the GPU has slots: there the chain length is the
-// kernel time, so the chunks shrink until the wavefronts fill the slots once (1024 x 3072: 14-15 rings, 128 x 384: 4).
-// (measured, profiles/r02_sweep_rows_mid.txt: isothermal grids are fastest with the wavefronts filling the slots
-//  once, the ideal-EOS kernels -- 4 wavefronts per SIMD, more loads per ring -- with about 1.8 rounds: 1024 x 3072
-//  0.305 ms per step with 14-15 rings per chunk, 0.283 with 6-10)
+// Rings per marching chunk.  A marching wavefront is a serial chain of (rows + pre-roll) ring iterations, and the
+// GPU holds a fixed number of them at a time (CUs x 4 SIMDs x the kernel's wavefronts per SIMD).  What a launch costs
+// is the number of ROUNDS of resident wavefronts -- an integer -- times the length of the chain: the chunk length
+// that minimises (rows + pre-roll) x rounds is taken.  Measured (round 2; 2048 rings unless noted):
+//   source march, ideal EOS, Nphi = 4096: 36 rings (3 990 wavefronts, one round) 0.5277 ms per step, 24 rings (two
+//     rounds, the second 47 % full) 0.5415, 35 rings (4 130 wavefronts: two rounds of long chains) 0.575; Nphi = 6144:
+//     54 rings 0.774 against 0.789 at 24; 1024 x 3072: 14 rings 0.2345-0.2362 against 0.2424 at 7;
+//   source march, isothermal, Nphi = 6144: 36 rings 0.5104-0.5148 against 0.5303-0.5322 at 24; Nphi = 4096: 24 rings
+//     (one round) 0.368, 23 (two) 0.397;
+//   transport: see transport_rows().
+// Small grids have fewer wavefronts than slots at any length: the shortest chunks (4 rings) win there.
 // compute units of the current device (one device per process)
 static int device_cus()
 {
@@ -135,48 +138,24 @@ static int device_cus()
     }
     return n_cu;
 }
-static int march_rows(int nrows, int tiles, int rows_max, int preroll, bool adiabatic)
-{
-    const double slots = adiabatic ? 7400.0 : 4096.0;
-    int best = rows_max;
-    double best_t = 1e300;
-    for (int r = 4; r <= rows_max; ++r) {
-        const double waves = (double)tiles * ((nrows + r - 1) / r);
-        const double t = (r + preroll) * (waves <= slots ? 1.0 : waves / slots);
-        if (t < best_t * (1.0 - 1e-9) || (t <= best_t * (1.0 + 1e-9) && r > best)) {
-            best_t = t;
-            best = r;
-        }
-    }
-    return best;
-}
 static int source_rows(const Dev &P)
 {
     if (P.opt.source_rows > 0)
         return P.opt.source_rows;
     const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
-    int r = march_rows(P.nr + 1, segs, 24, 4, P.adiabatic != 0);
-    // Grids whose wavefronts do not fit the GPU at once (at 24 rings per chunk): the source march costs the same in
-    // every chunk, so what counts is the number of ROUNDS of resident wavefronts, an integer, times the length of a
-    // chunk with its pre-roll.  Wavefronts per SIMD of the instantiation that will run: 6 (isothermal), 4 (with
-    // StabilizeViscosity; ideal EOS), 2 (ideal EOS with cooling terms or StabilizeViscosity).  Measured (round 2,
-    // 2048 rings): ideal EOS at Nphi = 4096 best with 36 (the first length that fits one round: 0.5277 against 0.5415
-    // ms per step at 24, 0.575 at 35), at 6144 with 54 (one round; 0.774 against 0.789); isothermal at 6144 with 36
-    // (0.5104-0.5148 against 0.5303-0.5322), at 4096 with 24 (23, two rounds: 0.397 against 0.368).
-    {
-        const bool wide_adi = P.adiabatic && (P.stabilize || P.cooling_surface || P.cooling_beta || P.heating_star);
-        const int occ = P.adiabatic ? (wide_adi ? 2 : 4) : (P.stabilize ? 4 : 6);
-        const long slots = (long)device_cus() * 4 * occ;
-        auto waves = [&](int rows) { return (long)segs * ((P.nr + 1 + rows - 1) / rows); };
-        if (waves(24) > slots) {
-            long best_cost = 0;
-            for (int rows = 12; rows <= 64; ++rows) {
-                const long cost = (rows + 4) * ((waves(rows) + slots - 1) / slots);
-                if (best_cost == 0 || cost < best_cost) {
-                    best_cost = cost;
-                    r = rows;
-                }
-            }
+    // wavefronts per SIMD of the instantiation that will run: 6 (isothermal), 4 (with StabilizeViscosity; ideal
+    // EOS), 2 (ideal EOS with cooling terms or StabilizeViscosity)
+    const bool wide_adi = P.adiabatic && (P.stabilize || P.cooling_surface || P.cooling_beta || P.heating_star);
+    const int occ = P.adiabatic ? (wide_adi ? 2 : 4) : (P.stabilize ? 4 : 6);
+    const long slots = (long)device_cus() * 4 * occ;
+    int r = 4;
+    long best_cost = 0;
+    for (int rows = 4; rows <= 64; ++rows) {
+        const long waves = (long)segs * ((P.nr + 1 + rows - 1) / rows);
+        const long cost = (rows + 4) * ((waves + slots - 1) / slots);
+        if (best_cost == 0 || cost < best_cost) {
+            best_cost = cost;
+            r = rows;
         }
     }
     // the boundary call folded into the kick needs the last chunk to hold rows nr-2 .. nr: a slightly longer chunk if
@@ -188,13 +167,36 @@ static int source_rows(const Dev &P)
     }
     return r;
 }
+// The transport deals whole chunks to the 8 XCDs (k_transport_fused), so the rounds are counted per XCD; and its
+// chunks are not equal: the rings of the damping zones (folded into the kernel) cost ~1.5x and are started first, which
+// adds half a round to the last one.  cost = (rows + 5) x (rounds - 1 + slow).  Measured: 2048 x 4096 (78 tiles): 20
+// rings (13 chunks per XCD, 1 014 wavefronts for 512 slots: 2 rounds) 0.363 ms per step; 18 (15 chunks: 3 rounds) 0.377;
+// 24 (2 rounds of longer chains) 0.367-0.371; 40 (7 chunks on some XCDs = 546 wavefronts: 2 rounds of 45) 0.41;
+// 1024 x 3072 ideal (58 tiles): 16 rings (8 chunks per XCD, one round) 0.2374-0.2383 against 0.2434-0.2448 at 8
+// and 0.250 at 14 (10 chunks per XCD: 580 wavefronts, two rounds).
 static int transport_rows(const Dev &P)
 {
     if (P.opt.transport_rows > 0)
         return P.opt.transport_rows;
     const int CF = 1; // cells per lane of the default kernel
     const int tstride = 64 * CF - (TfHalo<1>::lo + TfHalo<1>::hi);
-    return march_rows(P.nr, (P.nphi + tstride - 1) / tstride, TF_ROWS, 5, P.adiabatic != 0);
+    const long tiles = (P.nphi + tstride - 1) / tstride;
+    const long slots_xcd = (long)device_cus() / 8 * 4 * 4; // 4 wavefronts per SIMD (128 VGPRs)
+    const double slow = P.damp_in_step ? 1.5 : 1.0;
+    int r = 4;
+    double best_cost = 0.0;
+    for (int rows = 4; rows <= 32; ++rows) { // (longer single-round chains are unmeasured)
+        const long chunks = (P.nr + rows - 1) / rows;
+        // (launches of fewer than TF_XCD_CHUNKS chunks deal workgroups, not chunks: all wavefronts over all slots)
+        const long rounds = chunks >= TF_XCD_CHUNKS ? (((chunks + 7) / 8) * tiles + slots_xcd - 1) / slots_xcd
+                                                    : (chunks * tiles + 8 * slots_xcd - 1) / (8 * slots_xcd);
+        const double cost = (rows + 5) * (rounds - 1 + slow);
+        if (best_cost == 0.0 || cost < best_cost * (1.0 - 1e-12)) {
+            best_cost = cost;
+            r = rows;
+        }
+    }
+    return r;
 }
 // whole source step in one marching pass (Nphi >= 128); returns 0 if not applicable, else +-segments (> 0: ring sums
 // of v_phi were left for the transport).  fold_bc: the caller's next call is apply_boundary_condition(final = false) on

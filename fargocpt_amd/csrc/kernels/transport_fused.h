@@ -22,8 +22,6 @@
 // (10 + 11) doubles per cell for k_transport_radial + k_transport_theta_march.
 // Validity in cells of a 64*C segment: right 1 (L+ needs v_phi(j+1)), 4 at either end for the
 // two passes, left 1 for L+(j-1), 1 at either end for the v_r lane shift.
-#define TF_ROWS 20 /* rings per chunk on grids that fill the GPU several times over (fine sweep, round 2: 16 / 18 / 20 / 22 / 24 ->
-                      0.381 / 0.374 / 0.3715 / 0.380 / 0.375 ms per step at 2048 x 4096, ideal EOS 0.595 / - / 0.580 / - / 0.593) */
 // The chunks of one launch: `count` of them, the first `lead` are chunks 0..lead-1 of the grid, the others follow
 // `skip` chunks further up.  All chunks at once: {n, n, 0, 1}.  Slabs with neighbours march the chunks that hold
 // the rings the neighbours are waiting for first (fcpt_step_device_begin): {1 + tail, 1, gap, 1} then {gap, 0, 1, 0}.
