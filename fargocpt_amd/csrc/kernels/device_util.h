@@ -133,58 +133,34 @@ __device__ __forceinline__ double exp_small(double x)
 __device__ __forceinline__ double dmin(double a, double b) { return b < a ? b : a; } // std::min
 __device__ __forceinline__ double dmax(double a, double b) { return a < b ? b : a; } // std::max
 
-// Whole-wavefront shifts by one lane as DPP moves (gfx9 wave_shr:1 / wave_shl:1): the value of
-// lane-1 / lane+1, lanes 0 / 63 keep their own value.  Two VALU moves instead of two
-// ds_bpermute round trips through the LDS crossbar (profiles/tools/dpp_shift.hip).
-// The read-modify-write form costs a register copy per half (90 of the 770 vector instructions per
-// ring of k_transport_fused); the bound_ctrl form without it (FCPT_DPP_BOUND_CTRL: lanes 0 / 63 read 0,
-// parity-clean because those lanes are halo) removes them and measured 2 % SLOWER per step, three
-// A/B pairs in one session: the marching kernels are bound by dependent-issue latency, not by the
-// instruction count.
-template <int CTRL> __device__ __forceinline__ double dpp_shift(double x)
+// Whole-wavefront shifts by one lane as DPP moves (gfx9 wave_shr:1 / wave_shl:1): the value of lane-1 / lane+1.  Two
+// VALU moves instead of two ds_bpermute round trips through the LDS crossbar (profiles/tools/dpp_shift.hip).
+// Two forms.  bound_ctrl (KEEP = false, the default): lanes 0 / 63, which have no source lane, read 0 -- parity-clean,
+// those lanes are halo in every marching kernel -- and the moves need no prior copy of the destination.  Read-modify-
+// write (KEEP = true): lanes 0 / 63 keep their own value, at the price of a register copy per half (90 of the 770
+// vector instructions per ring of k_transport_fused).  History of the choice: bound_ctrl measured 2-4.5 % SLOWER
+// per step as long as the transport kernel's time was set by its tail of slow wavefronts; with the chunks dealt slow
+// ones first (transport_fused.h) the kernel sits at its issue bound and the same change is 1.2 % FASTER (isothermal,
+// three A/B pairs; the transport of the ideal EOS -9 us).  The ideal-EOS source march keeps the copies: without them
+// it runs 16 us longer (128 VGPRs, a different spill).
+// (Tried and dropped: the copy as one v_mov_b64, + 9 %; shifts through the LDS, + 16 %: 124 LDS operations of 512 B
+//  per ring and wavefront are as long on the CU's LDS port as the vector moves they replace.)
+template <int CTRL, bool KEEP> __device__ __forceinline__ double dpp_shift(double x)
 {
-#ifdef FCPT_DPP_BOUND_CTRL
+    if (KEEP) {
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
-#elif defined(FCPT_DPP_MOV64)
-    // the read-modify-write copy as ONE 64-bit move (gfx90a+ v_mov_b64) instead of the two v_mov_b32 the compiler emits
-    double t;
-    asm volatile("v_mov_b64 %0, %1" : "=v"(t) : "v"(x));
-    int lo = __double2loint(t), hi = __double2hiint(t);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-#else
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-#endif
 }
-#ifdef FCPT_LDS_SHIFT
-// Experiment: the neighbour's value through the LDS instead of DPP moves.  A wavefront writes its 64 values to its
-// own row and reads them back one slot to the left / right: two LDS instructions (their own issue port) instead of
-// four vector moves.  No barrier: a wavefront's LDS operations execute in order; lanes 0 / 63 read a padding slot
-// (those lanes are halo).  Blocks of at most 4 wavefronts.
-__device__ __forceinline__ double lds_shift(double x, int delta)
-{
-    __shared__ double s_shift[4][80];
-    typedef __attribute__((address_space(3))) double lds_double;
-    lds_double *row = (lds_double *)&s_shift[(threadIdx.x >> 6) & 3][8 + (threadIdx.x & 63)];
-    __builtin_amdgcn_wave_barrier(); // scheduling fence only: the LDS itself keeps a wavefront's operations in order
-    *row = x;
-    __builtin_amdgcn_wave_barrier();
-    const double v = row[delta];
-    __builtin_amdgcn_wave_barrier();
-    return v;
-}
-__device__ __forceinline__ double lane_prev(double x) { return lds_shift(x, -1); }
-__device__ __forceinline__ double lane_next(double x) { return lds_shift(x, 1); }
-#else
-__device__ __forceinline__ double lane_prev(double x) { return dpp_shift<0x138>(x); }
-__device__ __forceinline__ double lane_next(double x) { return dpp_shift<0x130>(x); }
-#endif
+__device__ __forceinline__ double lane_prev(double x) { return dpp_shift<0x138, false>(x); }
+__device__ __forceinline__ double lane_next(double x) { return dpp_shift<0x130, false>(x); }
+__device__ __forceinline__ double lane_prev_keep(double x) { return dpp_shift<0x138, true>(x); }
+__device__ __forceinline__ double lane_next_keep(double x) { return dpp_shift<0x130, true>(x); }
 // Sum over the wavefront in a fixed tree order (deterministic), all in the VALU: DPP row shifts
 // build the 16-lane row sums, row_bcast:15 / row_bcast:31 fold the four rows.  The total is valid
 // in lane 63.  (The ds_bpermute butterfly costs six dependent LDS round trips per call.)

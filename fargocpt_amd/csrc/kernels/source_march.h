@@ -334,8 +334,8 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
     const bool dissipate = P.art_visc_dissipation != 0;
     constexpr bool cooling = COOL;
 
-#define NEXT(x) lane_next(x) /* value of cell j+1 */
-#define PREV(x) lane_prev(x) /* value of cell j-1 */
+#define NEXT(x) lane_next_keep(x) /* value of cell j+1 (the read-modify-write form: see device_util.h) */
+#define PREV(x) lane_prev_keep(x) /* value of cell j-1 */
     auto crow = [nr](int r) { return r < 0 ? 0 : (r > nr - 1 ? nr - 1 : r); };   // cell rows
     auto vrow = [nr](int r) { return r < 0 ? 0 : (r > nr ? nr : r); };           // v_r rows
 
