@@ -525,8 +525,12 @@ __device__ __forceinline__ void theta_star(int lim, int lsrc_l, int lsrc_r, cons
         const double hm = c == 0 ? hl : h[c == 0 ? 0 : c - 1];
         if (MODE == 1)
             st[c] = wm + d2u * hm;
-        else
-            st[c] = (up[c] ? wm : W[c]) + d2[c] * (up[c] ? hm : h[c]);
+        else {
+            // both candidates with the lane's own distance factor, then ONE select (two v_cndmask) instead of two
+            // selects of the operands: the same value bit for bit
+            const double st_up = wm + d2[c] * hm, st_dn = W[c] + d2[c] * h[c];
+            st[c] = up[c] ? st_up : st_dn;
+        }
     }
 }
 

@@ -282,7 +282,9 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                     const double d0 = (w[0][q][c] - w[1][q][c]) * idr_m;
                     const double dprev = DIET ? (w[1][q][c] - w[2][q][c]) * idr_prev : d1[q][c];
                     const double hs0 = lim_ok ? half_limiter(lim, d0, dprev) : 0.0; // ring m-1
-                    const double st = (up[c] ? w[2][q][c] : w[1][q][c]) + dist[c] * (up[c] ? hs1[q][c] : hs0);
+                    // (both candidates with the lane's own distance, then one select: see theta_star)
+                    const double st_up = w[2][q][c] + dist[c] * hs1[q][c], st_dn = w[1][q][c] + dist[c] * hs0;
+                    const double st = up[c] ? st_up : st_dn;
                     if (q == 0) {
                         Fc[c] = open ? g * st * w[1][2][c] : 0.0; // mass flux g rho* v
                         F0[q][c] = Fc[c];
