@@ -34,27 +34,19 @@ template <int C> struct TfHalo {
     static constexpr int hi = 6;
 };
 
-// wave damping with the ring's precomputed exp(-dt f / tau) (k_ring_mean): types as damp_value.
-// ONE_BLOCK: the load of the reference value and its use in one basic block.  A load whose use sits behind another
-// branch leaves the compiler's s_waitcnt pass with a "maybe pending" register at every later store of the loop; the
-// ideal-EOS kernel, whose prefetch is pinned (see the bottom of its loop), needs this form, the isothermal one
-// measured 5 % slower with it (three A/B pairs) and keeps the other.
-template <bool ONE_BLOCK>
+// wave damping with the ring's precomputed exp(-dt f / tau) (k_ring_mean): types as damp_value.  The load of the
+// reference value and its use sit in one basic block: a load whose use is behind another branch leaves the compiler's
+// s_waitcnt pass with a "maybe pending" register at every later store of the loop, and the pinned prefetch (bottom
+// of the loop) would be waited for on the spot again.
 __device__ __forceinline__ double damp_apply(double X, int type, double ef, const double *ref, int cell, double zero_target)
 {
-    if (ONE_BLOCK) {
-        if (type == 1) {
-            const double X0 = ref[cell];
-            return (X - X0) * ef + X0;
-        }
-        if (type != 0)
-            return (X - zero_target) * ef + zero_target;
-        return X;
+    if (type == 1) {
+        const double X0 = ref[cell];
+        return (X - X0) * ef + X0;
     }
-    if (type == 0)
-        return X;
-    const double X0 = type == 1 ? ref[cell] : zero_target;
-    return (X - X0) * ef + X0;
+    if (type != 0)
+        return (X - zero_target) * ef + zero_target;
+    return X;
 }
 
 // THERM: the cell-local CFL terms of the new state are stored with it (ideal EOS; its own instantiation, because the
@@ -72,9 +64,11 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     // quantities of the rolling window instead of being carried along (ulp-level differences: e = (e / Sigma) Sigma,
     // v_phi = ((v_phi + r Omega) r) / r - r Omega)
     constexpr bool DIET = ADI;
-    // PIN: the prefetch of ring m+2 is pinned behind convert() of ring m+1 (bottom of the loop).  Ideal EOS only:
-    // -1.8 % per step there (four A/B pairs), no gain in the isothermal kernel.
-    constexpr bool PIN = ADI;
+    // PIN: the prefetch of ring m+2 is pinned behind convert() of ring m+1 (bottom of the loop).  -1.8 % per step for
+    // the ideal EOS when it was introduced; the isothermal kernel gained nothing then (its time was set by the tail of
+    // slow wavefronts) and 1.9 % once the chunks were dealt slow ones first (four A/B pairs each).
+    // DVP: v_phi re-derived from (v_phi + r Omega) r instead of carried: a carried copy would share the prefetch registers.
+    constexpr bool PIN = true, DVP = true;
     const int lane = threadIdx.x & 63;
     // Chunks are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8; all tiles of a chunk on one XCD, whose
     // L2 then serves their shared halo columns), in an order that starts at both ends of the slab and works inward:
@@ -147,7 +141,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     // rolling window: index 0 = ring m (newest), 1 = m-1, 2 = m-2
     double w[3][NQ][C];  // specific quantities: Sigma, v_r(ring+1), v_r(ring), (v_phi(j+1) + r Omega) r, (v_phi + r Omega) r(, e / Sigma)
     double er[DIET ? 1 : 3][C];     // the energy itself
-    double vp[DIET ? 1 : 3][C];     // v_phi as loaded
+    double vp[DVP ? 1 : 3][C];      // v_phi as loaded
     double d1[DIET ? 1 : NQ][C];    // (w(m-1) - w(m-2)) InvDiffRmed[m-1]
     double idr_prev = 0.0;          // DIET: InvDiffRmed[m-1], to re-form d1
     double hs1[NQ][C];   // limited half slope of ring m-2
@@ -162,7 +156,9 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                 d1[q][c] = 0.0;
         }
         if (!DIET)
-            er[0][c] = er[1][c] = er[2][c] = vp[0][c] = vp[1][c] = vp[2][c] = 0.0;
+            er[0][c] = er[1][c] = er[2][c] = 0.0;
+        if (!DVP)
+            vp[0][c] = vp[1][c] = vp[2][c] = 0.0;
         rmp_prev[c] = S_prev[c] = 0.0;
     }
     // raw loads of one ring: Sigma(k), v_phi(k)(, e(k)) and v_r(k+1); zeros outside the grid
@@ -222,7 +218,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                 if (!DIET)
                     er[0][c] = o.en[c];
             }
-            if (!DIET)
+            if (!DVP)
                 vp[0][c] = o.va[c];
             vr_last[c] = o.vr[c];
         }
@@ -318,7 +314,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                 for (int q = 0; q < 4; ++q)
                     Q[q][c] = s0 * w[2][q + 1][c] + (F1[q + 1][c] - F0[q + 1][c]) * invsurf;
                 E[c] = ADI ? (DIET ? s0 * w[2][NQ - 1][c] : er[2][c]) + (F1[NQ - 1][c] - F0[NQ - 1][c]) * invsurf : 0.0;
-                V[c] = vadd + ((DIET ? w[2][4][c] * ti.invr - ti.r_omega : vp[2][c]) - mean);
+                V[c] = vadd + ((DVP ? w[2][4][c] * ti.invr - ti.r_omega : vp[2][c]) - mean);
             }
             const double dxtheta = ti.dxtheta;
             const double invdx = ti.inv_dxtheta;
@@ -375,11 +371,11 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                     double e = ADI ? clamp_energy_fast(P, E[c], sf) : 0.0;
                     const int g = row + jout[c];
                     if (DAMP) {
-                        vr = damp_apply<ADI>(vr, di.tvr, si.ev, W.vrad0, g, 0.0);
-                        va = damp_apply<ADI>(va, di.tva, si.es, W.vazi0, g, 0.0);
-                        sf = damp_apply<ADI>(sf, di.tsg, si.es, W.sigma0, g, W.sigma_floor_abs);
+                        vr = damp_apply(vr, di.tvr, si.ev, W.vrad0, g, 0.0);
+                        va = damp_apply(va, di.tva, si.es, W.vazi0, g, 0.0);
+                        sf = damp_apply(sf, di.tsg, si.es, W.sigma0, g, W.sigma_floor_abs);
                         if (ADI)
-                            e = damp_apply<ADI>(e, di.ten, si.es, W.energy0, g, 0.0);
+                            e = damp_apply(e, di.ten, si.es, W.energy0, g, 0.0);
                     }
                     o_vr[c] = vr, o_va[c] = va, o_s[c] = sf, o_e[c] = e;
                     out_g[c] = g;
@@ -403,10 +399,10 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                 w[1][q][c] = w[0][q][c];
                 F1[q][c] = F0[q][c];
             }
-            if (!DIET) {
+            if (!DIET)
                 er[2][c] = er[1][c], er[1][c] = er[0][c];
+            if (!DVP)
                 vp[2][c] = vp[1][c], vp[1][c] = vp[0][c];
-            }
         }
         if (DIET)
             idr_prev = rk.idr_up;
@@ -463,7 +459,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                         double v = P.vrad[nr * nphi + jin[c]];
                         if (DAMP) {
                             const DampRow dn = crow_load(W.damp_tab, nr);
-                            v = damp_apply<ADI>(v, dn.tvr, si.ev_top, W.vrad0, nr * nphi + jin[c], 0.0);
+                            v = damp_apply(v, dn.tvr, si.ev_top, W.vrad0, nr * nphi + jin[c], 0.0);
                         }
                         W.vrad[nr * nphi + jin[c]] = v;
                     }
