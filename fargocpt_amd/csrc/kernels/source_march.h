@@ -60,7 +60,11 @@ __device__ __forceinline__ double visc_corr_march(double dt, double c) { return 
 // STAB: StabilizeViscosity 1 | 2 -- the correction factors are formed in stage E and stored (the CFL condition of
 // mode 2 and fcpt_download read the grids), mode 1 also damps the viscous velocity update with them.
 template <int AV, bool STAB> // AV 0: none, 1: TW, 2: SN
+#ifdef SM_TRACE /* profiles/tools/wave_trace.py: the wavefronts' end times, at the production occupancy */
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
+#else
 __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
+#endif
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -291,6 +295,10 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
             boundary_column(Q, j, sides);
         }
     }
+#ifdef SM_TRACE
+    if (lane == 0)
+        P.temperature[2 * wave + 1] = (double)wall_clock64(); // 10 ns ticks; the isothermal path does not use the grid
+#endif
 #undef NEXT
 #undef PREV
 }
