@@ -488,8 +488,14 @@ __device__ __forceinline__ double half_limiter(int type, double a, double b)
 {
     if (type == FCPT_LIMITER_MC)
         return 0.5 * limiter(type, a, b);
-    const double ab = a * b;
-    return ab > 0.0 ? ab * fast_rcp1(a + b) : 0.0;
+    // ab > 0 ? ab / (a + b) : 0 without the compare and the two selects: max(ab, 0) is the numerator, and the
+    // reciprocal is kept finite where a + b = 0 (then ab <= 0 and the product is an exact 0; a + b is +0, never -0:
+    // differences x - x round to +0).  For ab > 0 the operations are those of the select form, bit for bit.
+    const double ab = a * b, d = a + b;
+    double x = __builtin_amdgcn_rcp(d);
+    x = x < 1e300 ? x : 1e300; // v_min_f64
+    x = fma(x, fma(-d, x, 1.0), x);
+    return (ab > 0.0 ? ab : 0.0) * x; // v_max_f64
 }
 
 // Upwind star states of one quantity on the C cells of a lane (compute_star_theta,
