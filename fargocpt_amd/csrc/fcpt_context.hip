@@ -676,6 +676,19 @@ int fcpt_get_option(const fcpt_ctx *c, const char *name, int32_t *value)
 {
     if (!c || !name || !value)
         return FCPT_EINVAL;
+    // read-only counters of the hipGraph replay in fcpt_run_steps
+    if (!std::strcmp(name, "graph_replays")) {
+        *value = (int32_t)(c->graph_replays > 0x7fffffffll ? 0x7fffffffll : c->graph_replays);
+        return FCPT_OK;
+    }
+    if (!std::strcmp(name, "coop_active")) { // 1: fcpt_run_steps takes the one-kernel-per-step path on this grid
+        *value = c->coop_active ? 1 : 0;
+        return FCPT_OK;
+    }
+    if (!std::strcmp(name, "graph_cycle")) {
+        *value = c->graph_exec ? c->graph_cycle : 0;
+        return FCPT_OK;
+    }
     const int *slot = option_slot(const_cast<Options &>(c->P.opt), name);
     if (!slot) {
         set_error("fcpt_get_option: unknown option '%s'", name);
@@ -816,6 +829,7 @@ int fcpt_upload(fcpt_ctx *c, int32_t f, const double *host)
         c->stepped = false;
         c->thermal_valid = false;
         c->ghosts_unknown = true;
+        drop_graph(c); // its launches were chosen for ghost rings that satisfied the boundary conditions
     }
     if (f == FCPT_F_QPLUS || f == FCPT_F_QMINUS) {
         c->thermal_valid = false;

@@ -85,6 +85,8 @@ struct fcpt_ctx {
     hipGraph_t graph = nullptr;
     hipStream_t capture_stream = nullptr;
     int graph_cycle = 0;
+    bool coop_active = false; // the last fcpt_run_steps ran its steps as one cooperative kernel each
+    long long graph_replays = 0; // hipGraphLaunch calls issued so far (read-only option "graph_replays")
     bool graph_failed = false;
     Dev graph_P;
     unsigned graph_flags = 0;

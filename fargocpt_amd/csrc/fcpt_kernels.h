@@ -8,15 +8,21 @@
 
 namespace fcpt {
 
+// One id per __global__ function family; kKernelNames[id] is the function's name as rocprofv3 prints it (without
+// namespace and template arguments), so that fcpt_profile_stop's table can be matched to profiles/*.csv by name.
+// KID_CLOCK stands for the single-thread k_clock_* kernels (set_dt, scale_dt, advance, policy, policy_ptr, export_cfl).
 enum KernelId {
     KID_POTENTIAL, KID_SOURCE_VR, KID_SOURCE_VA, KID_COMPRESSION, KID_TW_Q, KID_TW_VA, KID_TW_VR,
     KID_SN_Q, KID_SN_E, KID_SN_VR, KID_SN_VA, KID_TRANGE, KID_ADI_CS_H, KID_ISO_CS_H,
     KID_VISCOSITY, KID_PRESSURE, KID_TEMPERATURE, KID_STRESS_DIAG, KID_STRESS_RPHI, KID_VISC_VA,
     KID_VISC_VR, KID_QPLUS, KID_SUBSTEP3, KID_BOUNDARY, KID_DAMPING, KID_TRANSPORT_RADIAL,
     KID_RING_MEAN, KID_THETA1, KID_THETA2, KID_VELOCITIES, KID_CFL_INIT, KID_CFL_CELLS, KID_CLOCK,
-    KID_SRC_FUSED, KID_AV_FUSED, KID_VISC_FUSED, KID_SOURCE_MARCH, KID_THETA_FUSED, KID_THETA_MARCH,
-    KID_TRANSPORT_FUSED, KID_MASSFLOW, KID_COUNT
+    KID_SRC_FUSED, KID_AV_FUSED, KID_VISC_FUSED, KID_SOURCE_MARCH, KID_THETA_MARCH,
+    KID_TRANSPORT_FUSED, KID_MASSFLOW, KID_CFL_RINGS, KID_TRANSPORT_FALLBACK, KID_EXCHANGE_COPY,
+    KID_DISK_ON_BODY, KID_VISC_FACTORS, KID_SOURCE_MARCH_ADI, KID_SOURCE_MARCH_ADI_WIDE,
+    KID_TRANSPORT_FUSED_THERM, KID_TRANSPORT_FUSED_WIDE, KID_STEP_COOP, KID_COUNT
 };
+static_assert(KID_COUNT <= 64, "fcpt_profile_start selects kernels with a 64-bit mask");
 extern const char *const kKernelNames[KID_COUNT];
 
 // HIP-event stopwatch around selected kernel launches (on the launch stream).

@@ -141,7 +141,8 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool spl
     // (after an upload of a state grid the ghost rings may not satisfy the boundary conditions yet: the folded form
     //  rewrites Sigma's ghost ring while neighbouring wavefronts may still read it -- harmless only when the values
     //  are the ones already there, so that one step takes the separate launch)
-    const bool in_b = enqueue_kick(c, !c->ghosts_unknown);
+    //  likewise a second fcpt_step without fcpt_post in between: the ghost rings are the transport's, not a boundary call's)
+    const bool in_b = enqueue_kick(c, !c->ghosts_unknown && !c->stepped);
     c->ghosts_unknown = false;
     Dev Q = P; // view with the post-kick velocities
     if (in_b) {
@@ -426,7 +427,7 @@ unsigned launch_flags(const fcpt_ctx *c)
     return (c->potential_valid ? 1u : 0u) | (c->pressure_valid ? 2u : 0u) | (c->stepped ? 4u : 0u) |
            (c->cfl_interior ? 8u : 0u) | (c->kick_energy_b ? 16u : 0u) | (c->fused_source ? 32u : 0u) |
            (c->march_source ? 64u : 0u) | (c->has_mid ? 128u : 0u) | (c->join_pending ? 256u : 0u) |
-           (c->thermal_valid ? 512u : 0u) |
+           (c->thermal_valid ? 512u : 0u) | (c->ghosts_unknown ? 1024u : 0u) | (c->qdiff_valid ? 2048u : 0u) |
            ((unsigned)c->src_parts << 12);
 }
 bool graph_wanted(const fcpt_ctx *c)
@@ -480,6 +481,8 @@ bool capture_graph(fcpt_ctx *c, int cycle)
         c->cfl_interior = f0 & 8u;
         c->kick_energy_b = f0 & 16u;
         c->thermal_valid = f0 & 512u;
+        c->ghosts_unknown = f0 & 1024u;
+        c->qdiff_valid = f0 & 2048u;
         c->src_parts = (int)(f0 >> 12);
         drop_graph(c);
         return false;
@@ -558,8 +561,10 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
                     c->graph_failed = true;
             }
             if (c->graph_exec) {
-                for (; n + c->graph_cycle <= nsteps; n += c->graph_cycle)
+                for (; n + c->graph_cycle <= nsteps; n += c->graph_cycle) {
                     HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+                    ++c->graph_replays;
+                }
             }
         }
         for (; n < nsteps; ++n)

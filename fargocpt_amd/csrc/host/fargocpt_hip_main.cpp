@@ -10,8 +10,10 @@
 //
 // Supported configuration keys: the ones the hot path consumes (SURVEY.md section 5 "Config /
 // flags"); unit suffixes au / solMass / jupiterMass / earthMass / g/cm2 / K are understood
-// for the default unit system (l0 = 1 au, m0 = 1 solMass).  Unknown keys are ignored with a
-// warning unless -q (the reference treats them as fatal: src/config.cpp:134-138).
+// for the default unit system (l0 = 1 au, m0 = 1 solMass).  A key the reference's reader does not know is
+// fatal, as in the reference (src/config.cpp:134-138: a typo must not silently change the physics); --lenient
+// downgrades that to a warning.  Keys the reference knows but the gas path does not consume are accepted (listed
+// unless -q); features outside the path that a setup switches on (self-gravity, particles, FLD ...) are refused.
 #include "../../../include/fargocpt_hip.h"
 
 #include <algorithm>
@@ -113,6 +115,64 @@ struct Config {
         return !v.empty() && (v[0] == 'y' || v[0] == 't' || v[0] == '1');
     }
 };
+
+// Every top-level key the reference's own reader visits (config::cfg.get* / contains calls of src/parameters.cpp,
+// src/Interpret.cpp, src/units.cpp, src/boundary_conditions/{config,damping}.cpp, src/particles, src/fld ..., lower
+// case): a key outside this set is what src/config.cpp:134-138 dies on ("Unknown key(s) found in config file").
+const char *const kReferenceKeys[] = {
+    "accretewithoutdiskfeedback", "adiabatic", "adiabaticindex", "alphacold", "alphahot", "alphamode",
+    "artificialviscosity", "artificialviscositydissipation", "artificialviscosityfactor", "aspectratio",
+    "aspectratiomode", "bitwiseexactrestarting", "bodyforcefrompotential", "cartesianparticles",
+    "centerprofiledensitycorrectionfactor", "cfl", "cflmaxvar", "cicplanet", "circumbinarydecayexponent",
+    "circumbinarydecaywidth", "circumbinaryring", "circumbinaryringenhancementfactor", "circumbinaryringposition",
+    "circumbinaryringwidth", "compatibilitynostarsmoothing", "compatibilitysmoothingplanetloc", "constantviscosity",
+    "coolingbeta", "coolingbetalocal", "coolingbetarampup", "coolingbetareference", "coolingbetaziampras2023",
+    "coolingbetaziampras2023method", "coolingradiativefactor", "corotationreferencebody", "correctdiskselfgravity",
+    "cps", "cvnr", "damping", "dampingenergyinner", "dampingenergyouter", "dampinginnerlimit", "dampingouterlimit",
+    "dampingsurfacedensityinner", "dampingsurfacedensityouter", "dampingtimefactor", "dampingtimeradiusouter",
+    "dampingvazimuthalinner", "dampingvazimuthalouter", "dampingvradialinner", "dampingvradialouter",
+    "densityfactor", "disk", "diskfeedback", "diskmass", "diskradiusmassfraction", "dowrite1dfiles",
+    "energycondition", "energyfilename", "equationofstate", "exponentialcellsizefactor", "featuresize", "firstdt",
+    "flaringindex", "fluxlimiter", "frame", "heatingcoolingcfllimit", "heatingviscous", "heatingviscousfactor",
+    "hydroframecenter", "hydrogenmassfraction", "imposeddiskdrift", "indirecttermdiskondisk", "indirecttermmode",
+    "initializepurekeplerian", "initializevradialzero", "innerboundary", "innerboundaryenergy", "innerboundarysigma",
+    "innerboundaryvazi", "innerboundaryvazikeplerianfactor", "innerboundaryvrad", "innerboundaryvradkeplerianfactor",
+    "integrateparticles", "integrator", "kappaconst", "kappafactor", "keepdiskmassconstant", "klahrsmoothingradius",
+    "l0", "logafterrealseconds", "logaftersteps", "m0", "massaccretionradius", "maximumtemperature",
+    "minimumtemperature", "monitortimestep", "mu", "naz", "nbody", "nmonitor", "nrad", "nsnapshots",
+    "numberofparticles", "omegaframe", "opacity", "outerboundary", "outerboundaryenergy", "outerboundarysigma",
+    "outerboundaryvazi", "outerboundaryvazikeplerianfactor", "outerboundaryvrad", "outerboundaryvradkeplerianfactor",
+    "outputdir", "particledensity", "particlediskgravityenabled", "particledustdiffusion", "particleeccentricity",
+    "particlegasdragenabled", "particleintegrator", "particlemaximumescaperadius", "particlemaximumradius",
+    "particleminimumescaperadius", "particleminimumradius", "particleradius", "particleradiusincreasefactor",
+    "particlespeciesnumber", "particlesurfacedensityslope", "planetorbitdisktest", "polytropicconstant",
+    "profilecutoffinner", "profilecutoffouter", "profilecutoffpointinner", "profilecutoffpointouter",
+    "profilecutoffwidthinner", "profilecutoffwidthouter", "quantitiesradiuslimit", "radialspacing",
+    "radialviscosityfactor", "radiativediffusion", "radiativediffusionautoomega", "radiativediffusionchecksolution",
+    "radiativediffusiondumpdata", "radiativediffusioninnerboundary", "radiativediffusionmaxiterations",
+    "radiativediffusionomega", "radiativediffusionouterboundary", "radiativediffusiontest1d",
+    "radiativediffusiontest2d", "radiativediffusiontest2ddensity", "radiativediffusiontest2dk",
+    "radiativediffusiontest2dsteps", "radiativediffusiontolerance", "randomfactor", "randomseed", "randomsigma",
+    "rmax", "rmin", "rochelobeoverflow", "rofaveragingtime", "rofgamma", "rofplanet", "roframpingtime",
+    "roftemperature", "rofvalue", "rofvariabletransfer", "scurvetype", "secondarydisk", "selfgravity",
+    "selfgravityaspectratiochangethreshold", "selfgravitymode", "selfgravitystepsbetweenkernelupdate", "setsigma0",
+    "shocktube", "sigma0", "sigmacondition", "sigmafilename", "sigmafloor", "sigmaslope", "spreadingring",
+    "stabilizeviscosity", "surfacecooling", "t0", "taufactor", "taumin", "temp0", "temperature0",
+    "thicknesssmoothing", "thicknesssmoothingsg", "transport", "vazimuthalconsidersquadropolemoment",
+    "viscaccretmassflowtest", "viscousalpha", "viscousoutflowspeed", "writealpha", "writealphagrav",
+    "writealphagravmean", "writealphareynolds", "writealphareynoldsmean", "writeaspectratio", "writeateverytimestep",
+    "writedefaultvalues", "writedensity", "writediskquantities", "writedivv", "writeeccentricity",
+    "writeeccentricitychange", "writeeffectivegamma", "writeenergy", "writefirstadiabaticindex", "writegastorques",
+    "writekappa", "writelightcurves", "writelightcurvesradii", "writemassflow", "writemeanmolecularweight",
+    "writepdv", "writepotential", "writepressure", "writeqminus", "writeqplus", "writeradialdissipation",
+    "writeradialluminosity", "writescaleheight", "writesgaccelazi", "writesgaccelrad", "writesoundspeed", "writetau",
+    "writetaucool", "writetemperature", "writetgravitational", "writetoomre", "writetorques", "writetreynolds",
+    "writevelocity", "writeverticalopticaldepth", "writeviscosity", "writevisibility",};
+// Features of the reference outside the gas path of this driver: a setup that switches one on is refused, not run
+// without it (out of scope).
+const char *const kRefusedWhenOn[] = {"selfgravity", "integrateparticles", "radiativediffusion", "rochelobeoverflow",
+                                      "keepdiskmassconstant", "circumbinaryring", "planetorbitdisktest",
+                                      "viscaccretmassflowtest"};
 
 // code units (set_baseunits, src/units.cpp:131-185): l0 and m0 from the setup (default 1 au, 1 solMass), time and
 // temperature units derived with G = 1 and R_gas = 1
@@ -456,13 +516,15 @@ struct misc_entry { // src/output.h:16-24
 
 int main(int argc, char **argv)
 {
-    bool quiet = false;
+    bool quiet = false, lenient = false;
     long max_steps = -1, restart_from = -1;
     std::string mode, cfgpath;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-q")
             quiet = true;
+        else if (a == "--lenient")
+            lenient = true;
         else if (a == "-N" && i + 1 < argc)
             max_steps = atol(argv[++i]);
         else if (mode.empty())
@@ -514,12 +576,31 @@ int main(int argc, char **argv)
         }
     }
     const bool restarting = mode == "restart";
-    // keys the path does not consume are tolerated here (the reference dies on unknown keys)
-    if (!quiet)
-        for (auto &kv : cfg.kv)
-            if (!cfg.used.count(kv.first) && kv.first.compare(0, 5, "write") != 0 &&
-                kv.first.compare(0, 8, "particle") != 0)
+    { // config::Config::exit_on_unknown_key (src/config.cpp:119-138, called at src/main.cpp:111-113)
+        std::string unknown;
+        for (auto &kv : cfg.kv) {
+            bool known = false;
+            for (const char *k : kReferenceKeys)
+                known = known || kv.first == k;
+            if (!known)
+                unknown += (unknown.empty() ? "" : ", ") + kv.first;
+            else if (!quiet && !cfg.used.count(kv.first) && kv.first.compare(0, 5, "write") != 0 &&
+                     kv.first.compare(0, 8, "particle") != 0)
                 fprintf(stderr, "fargocpt_hip: note: key '%s' is not used by the gas path\n", kv.first.c_str());
+        }
+        if (!unknown.empty()) {
+            fprintf(stderr, "%sUnknown key(s) found in config file: '%s'\nMaybe there is a typo?\n",
+                    lenient ? "fargocpt_hip: warning: " : "", unknown.c_str());
+            if (!lenient)
+                return 1;
+        }
+        for (const char *k : kRefusedWhenOn)
+            if (cfg.has(k) && cfg.flag(k, false)) {
+                fprintf(stderr, "fargocpt_hip: '%s' is switched on, but that part of the reference is outside this driver's "
+                                "gas path\n", k);
+                return 2;
+            }
+    }
 
     // bodies: star + planets on fixed circular orbits
     std::vector<Body> bodies;

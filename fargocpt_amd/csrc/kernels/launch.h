@@ -5,12 +5,14 @@
 // per-kernel HIP-event timing (fcpt_profile_start/stop)
 const char *const kKernelNames[KID_COUNT] = {
     "k_potential", "k_source_vr", "k_source_va", "k_compression_heating", "k_tw_q", "k_tw_va", "k_tw_vr",
-    "k_sn_q", "k_sn_e", "k_sn_vr", "k_sn_va", "k_temperature_range", "k_adi_cs_h", "k_iso_cs_h",
+    "k_sn_q", "k_sn_e", "k_sn_vr", "k_sn_va", "k_temperature_range", "k_adi_derived", "k_iso_cs_h",
     "k_viscosity", "k_pressure", "k_temperature", "k_stress_diag", "k_stress_rphi", "k_visc_va",
     "k_visc_vr", "k_qplus_qminus", "k_substep3", "k_boundary", "k_damping", "k_transport_radial",
-    "k_ring_mean", "k_transport_theta1", "k_transport_theta2", "k_velocities", "k_cfl_final",
+    "k_ring_mean", "k_transport_theta<1>", "k_transport_theta<2>", "k_velocities", "k_cfl_final",
     "k_cfl_cells", "k_clock", "k_src_fused", "k_av_fused", "k_visc_fused", "k_source_march",
-    "k_transport_theta_fused", "k_transport_theta_march", "k_transport_fused", "k_massflow"};
+    "k_transport_theta_march", "k_transport_fused", "k_massflow", "k_cfl_rings", "k_transport_fallback",
+    "k_exchange_copy", "k_disk_on_body", "k_visc_factors", "k_source_march_adi", "k_source_march_adi_wide",
+    "k_transport_fused_therm", "k_transport_fused_wide", "k_step_coop"};
 
 thread_local Profiler *g_prof = nullptr;
 
@@ -230,16 +232,16 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
         const int ring_sums = segs <= P.ring_pstride && P.opt.source_ring_parts != 0;
 #define ADIKS(AV_, COOL_, POT_)                                                                                               \
     if (P.stabilize)                                                                                                          \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi_wide<AV_, COOL_, POT_, true>), grid, block, P, segs, rows, ring_sums, bc_fold); \
+        KLAUNCH(KID_SOURCE_MARCH_ADI_WIDE, (k_source_march_adi_wide<AV_, COOL_, POT_, true>), grid, block, P, segs, rows, ring_sums, bc_fold); \
     else                                                                                                                      \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi_wide<AV_, COOL_, POT_, false>), grid, block, P, segs, rows, ring_sums, bc_fold)
+        KLAUNCH(KID_SOURCE_MARCH_ADI_WIDE, (k_source_march_adi_wide<AV_, COOL_, POT_, false>), grid, block, P, segs, rows, ring_sums, bc_fold)
 #define ADIKP(AV_, POT_)                                                                                    \
     if (cool) {                                                                                             \
         ADIKS(AV_, true, POT_);                                                                             \
     } else if (P.stabilize) {                                                                               \
         ADIKS(AV_, false, POT_);                                                                            \
     } else {                                                                                                \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march_adi<AV_, POT_>), grid, block, P, segs, rows, ring_sums, bc_fold); \
+        KLAUNCH(KID_SOURCE_MARCH_ADI, (k_source_march_adi<AV_, POT_>), grid, block, P, segs, rows, ring_sums, bc_fold); \
     }
 #define ADIK(AV_)            \
     if (P.inline_potential) { \
@@ -296,7 +298,7 @@ void launch_substep3_after_fused(const Dev &P, hipStream_t st)
 void launch_visc_factors(const Dev &P, hipStream_t st)
 {
     if (P.stabilize)
-        LAUNCH2D(KID_STRESS_RPHI, k_visc_factors, P.nr - 1, P);
+        LAUNCH2D(KID_VISC_FACTORS, k_visc_factors, P.nr - 1, P);
 }
 void launch_stress(const Dev &P, hipStream_t st)
 {
@@ -343,7 +345,7 @@ void launch_exchange_copy(const Dev &P, double *inner, double *outer, int unpack
     const size_t npair = ((size_t)FCPT_OVERLAP * P.nphi) >> 1;
     int bx = (int)((npair + 255) / 256);
     bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
-    KLAUNCH(KID_BOUNDARY, k_exchange_copy, dim3(bx, 2 * a.nq), dim3(256), a);
+    KLAUNCH(KID_EXCHANGE_COPY, k_exchange_copy, dim3(bx, 2 * a.nq), dim3(256), a);
 }
 
 void launch_boundary(const Dev &P, hipStream_t st)
@@ -441,14 +443,14 @@ static void launch_fallback(const Dev &P, const Dev &Wm, hipStream_t st)
     const dim3 grid(blocks), block(256);
     if (P.adiabatic) {
         if (Wm.damp_in_step)
-            KLAUNCH(KID_TRANSPORT_RADIAL, (k_transport_fallback<true, true>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
+            KLAUNCH(KID_TRANSPORT_FALLBACK, (k_transport_fallback<true, true>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
         else
-            KLAUNCH(KID_TRANSPORT_RADIAL, (k_transport_fallback<true, false>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
+            KLAUNCH(KID_TRANSPORT_FALLBACK, (k_transport_fallback<true, false>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
     } else {
         if (Wm.damp_in_step)
-            KLAUNCH(KID_TRANSPORT_RADIAL, (k_transport_fallback<false, true>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
+            KLAUNCH(KID_TRANSPORT_FALLBACK, (k_transport_fallback<false, true>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
         else
-            KLAUNCH(KID_TRANSPORT_RADIAL, (k_transport_fallback<false, false>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
+            KLAUNCH(KID_TRANSPORT_FALLBACK, (k_transport_fallback<false, false>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
     }
 }
 // the fused kernel runs, nothing is queued behind it, and there are chunks between the two ends
@@ -510,18 +512,18 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         res.split = part != TRANSPORT_ALL;
         // (8 XCDs x the wavefronts of ceil(count / 8) chunks, four to a workgroup: see the chunk mapping in the kernel)
         const dim3 grid(ch.count >= TF_XCD_CHUNKS ? 8 * ((((ch.count + 7) / 8) * tiles + 3) / 4) : (ch.count * tiles + 3) / 4), block(256);
-#define TFK2(KK, CC, AA, DD)                                                                                        \
-    if (P.limiter == FCPT_LIMITER_MC)                                                                                \
-        KLAUNCH(KID_TRANSPORT_FUSED, (KK<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback, ch); \
-    else                                                                                                             \
-        KLAUNCH(KID_TRANSPORT_FUSED, (KK<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, fallback, ch)
+#define TFK2(ID, KK, CC, AA, DD)                                                                    \
+    if (P.limiter == FCPT_LIMITER_MC)                                                                \
+        KLAUNCH(ID, (KK<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback, ch); \
+    else                                                                                             \
+        KLAUNCH(ID, (KK<CC, AA, DD, FCPT_LIMITER_VANLEER>), grid, block, P, Wm, tiles, rows, fallback, ch)
 #define TFK(CC, AA, DD)                                \
     if (CC == 1 && AA && Wm.cfl_thermal) {             \
-        TFK2(k_transport_fused_therm, 1, true, DD);    \
+        TFK2(KID_TRANSPORT_FUSED_THERM, k_transport_fused_therm, 1, true, DD); \
     } else if (CC == 1) {                              \
-        TFK2(k_transport_fused, 1, AA, DD);            \
+        TFK2(KID_TRANSPORT_FUSED, k_transport_fused, 1, AA, DD); \
     } else {                                           \
-        TFK2(k_transport_fused_wide, 2, AA, DD);       \
+        TFK2(KID_TRANSPORT_FUSED_WIDE, k_transport_fused_wide, 2, AA, DD); \
     }
 #define TFC(CC)                    \
     if (P.adiabatic) {             \
@@ -616,8 +618,8 @@ void launch_disk_on_body(const Dev &P, double x, double y, double r_object, doub
 {
     const int nrows = P.active_size - P.first_active;
     const dim3 grid((P.nphi + 255) / 256, nrows > 0 ? (nrows + DOB_ROWS - 1) / DOB_ROWS : 1), block(256);
-    KLAUNCH(KID_POTENTIAL, k_disk_on_body, grid, block, P, x, y, r_object, smoothing_fixed, r_sm, P.cfl_part);
-    KLAUNCH(KID_POTENTIAL, k_disk_on_body_final, dim3(1), dim3(256), (const double *)P.cfl_part, (int)(grid.x * grid.y), out);
+    KLAUNCH(KID_DISK_ON_BODY, k_disk_on_body, grid, block, P, x, y, r_object, smoothing_fixed, r_sm, P.cfl_part);
+    KLAUNCH(KID_DISK_ON_BODY, k_disk_on_body_final, dim3(1), dim3(256), (const double *)P.cfl_part, (int)(grid.x * grid.y), out);
 }
 
 // rings whose CFL terms read nothing the ghost exchange or the boundary kernels write: ring i reads rows i
@@ -637,13 +639,13 @@ static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, int f
         return;
     const bool wide = P.nphi > 512 * CFL_MAXP;
     if (P.adiabatic && wide)
-        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<true, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
+        KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<true, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
     else if (P.adiabatic)
-        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<true, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
+        KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<true, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
     else if (wide)
-        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<false, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
+        KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
     else
-        KLAUNCH(KID_CFL_CELLS, (k_cfl_rings<false, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
+        KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
 }
 // phase 1 of a split CFL: the interior rings only (returns false when the one-block-per-ring kernel does not apply)
 bool launch_cfl_interior(const Dev &P, hipStream_t st)

@@ -64,3 +64,16 @@ def test_world_size_must_match_gpus():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run-ranks"], env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_a_dying_rank_ends_the_run_instead_of_hanging_it():
+    """rank 1 exits before the rendezvous; rank 0 would wait in it forever.  The parent polls all
+    children, ends the survivors and reports the exit codes."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run-ranks", "--dry-run-fail-rank", "1"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1
+    assert r.stdout.strip() == ""
+    assert "rank 1 exited with code 3" in r.stderr
+    assert time.monotonic() - t0 < 120

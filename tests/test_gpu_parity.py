@@ -440,12 +440,12 @@ def test_cfl_split_around_the_ghost_exchange(product, adiabatic, rank, nranks, m
                 if b is not None:
                     b.mul_(1.0 + 1.0e-4)
             torch.cuda.synchronize()
-            ctx.profile_start([names.index("k_cfl_cells")], max_launches=8)
+            ctx.profile_start([names.index("k_cfl_rings")], max_launches=8)
             ctx.cfl_begin()
             ctx.exchange_unpack(ptr(bufs[0]), ptr(bufs[1]))
             ctx.post(dt)
             dts.append(ctx.cfl())
-            launches += ctx.profile_stop()["k_cfl_cells"][1]
+            launches += ctx.profile_stop()["k_cfl_rings"][1]
         got.append((dts, launches, ctx.state()))
         ctx.close()
     assert got[0][0] == got[1][0]
