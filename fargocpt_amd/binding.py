@@ -11,7 +11,7 @@ from typing import Optional
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OVERLAP = 7
 GEOM_PAD = 15
 MAX_BODIES = 8
@@ -176,6 +176,14 @@ class Library:
     def create(self, d: Desc, radii: np.ndarray) -> "Context":
         return Context(self, d, radii)
 
+    def device_count(self) -> int:
+        n = _i32()
+        self.check(self.fn("device_count")(C.byref(n)), "device_count")
+        return n.value
+
+    def set_device(self, device: int):
+        self.check(self.fn("set_device")(_i32(device)), "set_device")
+
     def comm_unique_id(self) -> bytes:
         """ncclGetUniqueId: slab 0 calls it and hands the bytes to every slab (fcpt_comm_init)."""
         buf = C.create_string_buffer(COMM_ID_BYTES)
@@ -245,6 +253,13 @@ class Context:
     def comm_init(self, unique_id: bytes):
         assert len(unique_id) == COMM_ID_BYTES
         self._call("comm_init", C.c_char_p(unique_id))
+
+    def comm_init_host(self, path: str):
+        """The host-staged transport (several slabs on one GPU): a shared-memory file instead of RCCL."""
+        self._call("comm_init_host", C.c_char_p(path.encode()))
+
+    def comm_barrier(self):
+        self._call("comm_barrier")
 
     def comm_destroy(self):
         self._call("comm_destroy")

@@ -21,6 +21,12 @@ struct Comm;
 int comm_unique_id(void *id128);
 // ncclCommInitRank on the current HIP device; collective over all `nranks` callers
 int comm_create(const void *id128, int rank, int nranks, Comm **out);
+// The same two operations for ranks that cannot use RCCL among themselves (several ranks on one GPU: tests, or more
+// slabs than devices): ghost rings and the CFL value are staged through pinned host buffers and a shared-memory
+// file `path` (created by rank 0; one file per run), `count` doubles per message.  Blocks the host in every
+// operation -- a rehearsal transport, not a fast one.
+int comm_create_host(const char *path, int rank, int nranks, size_t count, Comm **out);
+bool comm_is_host_staged(const Comm *c);
 void comm_destroy(Comm *c);
 int comm_rank(const Comm *c);
 int comm_size(const Comm *c);
@@ -28,6 +34,8 @@ int comm_size(const Comm *c);
 int comm_neighbour_exchange(Comm *c, int peer_inner, const double *send_inner, double *recv_inner, int peer_outer,
                             const double *send_outer, double *recv_outer, size_t count, hipStream_t st);
 int comm_allreduce_min(Comm *c, double *d_value, hipStream_t st);
+// MPI_Barrier (+ completion of the work queued on st)
+int comm_barrier(Comm *c, hipStream_t st);
 
 } // namespace fcpt
 #endif

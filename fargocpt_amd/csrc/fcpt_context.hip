@@ -188,6 +188,34 @@ int copy_initial_values(fcpt_ctx *c)
 
 extern "C" {
 
+int fcpt_device_count(int32_t *n)
+{
+    if (!n)
+        return FCPT_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) {
+        (void)hipGetLastError();
+        ndev = 0;
+    }
+    *n = ndev;
+    return FCPT_OK;
+}
+
+int fcpt_set_device(int32_t device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available");
+        return FCPT_ENODEV;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("fcpt_set_device(%d): %d device(s) visible", device, ndev);
+        return FCPT_EINVAL;
+    }
+    HIPCHK(hipSetDevice(device));
+    return FCPT_OK;
+}
+
 int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
 {
     if (!d || !radii || !out) {
@@ -205,10 +233,6 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     }
     if (!d->body_force_from_potential) {
         set_error("BodyForceFromPotential: no is not supported");
-        return FCPT_EINVAL;
-    }
-    if ((d->cooling_surface || d->cooling_beta) && d->eos != FCPT_EOS_IDEAL) {
-        set_error("cooling needs EquationOfState: ideal");
         return FCPT_EINVAL;
     }
     if (d->cooling_surface && d->opacity != FCPT_OPACITY_LIN && d->opacity != FCPT_OPACITY_CONST &&
@@ -235,6 +259,9 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     if (!c)
         return FCPT_ENOMEM;
     c->d = *d;
+    if (d->eos != FCPT_EOS_IDEAL) // no energy equation: SubStep3 and with it every cooling term is not called
+        c->d.cooling_surface = c->d.cooling_beta = 0; // (simulation.cpp:205-207 `if (parameters::Adiabatic)`)
+    d = &c->d;
     (void)hipGetDevice(&c->device);
     if (int rc = split_domain(*d, c->s)) {
         delete c;

@@ -86,6 +86,32 @@ int fcpt_comm_unique_id(void *id128)
     return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
 }
 
+} // extern "C"
+namespace {
+// what a context needs around either communicator: neighbours, ghost-ring buffers, the all-reduce's scalar, the
+// communication stream of comm_overlap
+int comm_attach(fcpt_ctx *c, bool loopback, int rank)
+{
+    c->peer_inner = loopback ? 0 : (c->s.is_first ? -1 : rank - 1);
+    c->peer_outer = loopback ? 0 : (c->s.is_last ? -1 : rank + 1);
+    uint64_t cnt = 0;
+    (void)fcpt_exchange_count(c, &cnt);
+    int rc = FCPT_OK;
+    for (int k = 0; k < 4 && !rc; ++k)
+        if (!c->xbuf[k])
+            rc = dev_alloc(c, &c->xbuf[k], (size_t)cnt);
+    if (!rc && !c->d_cfl)
+        rc = dev_alloc(c, &c->d_cfl, 1);
+    if (rc)
+        return rc;
+    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->e_packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->e_received, hipEventDisableTiming));
+    return FCPT_OK;
+}
+} // namespace
+extern "C" {
+
 int fcpt_comm_init(fcpt_ctx *c, const void *id128)
 {
     if (!c || !id128)
@@ -102,21 +128,44 @@ int fcpt_comm_init(fcpt_ctx *c, const void *id128)
     const int rank = loopback ? 0 : c->d.rank, nranks = loopback ? 1 : c->d.nranks;
     if (int rc = comm_create(id128, rank, nranks, &c->comm))
         return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
-    c->peer_inner = loopback ? 0 : (c->s.is_first ? -1 : rank - 1);
-    c->peer_outer = loopback ? 0 : (c->s.is_last ? -1 : rank + 1);
+    return comm_attach(c, loopback, rank);
+}
+
+// The host-staged transport (fcpt_comm.h): the same fcpt_exchange / fcpt_cfl_allreduce / fcpt_run_steps, for ranks
+// that share a GPU
+int fcpt_comm_init_host(fcpt_ctx *c, const char *path)
+{
+    if (!c || !path)
+        return FCPT_EINVAL;
+    if (c->comm) {
+        set_error("fcpt_comm_init_host: the context already has a communicator");
+        return FCPT_EINVAL;
+    }
+    if (c->P.opt.comm_loopback != 0) {
+        set_error("fcpt_comm_init_host: the loopback rehearsal is an RCCL mode");
+        return FCPT_EINVAL;
+    }
+    if (c->P.nr < 2 * FCPT_OVERLAP && c->d.nranks > 1)
+        return FCPT_ESPLIT;
+    HIPCHK(hipSetDevice(c->device));
     uint64_t cnt = 0;
     (void)fcpt_exchange_count(c, &cnt);
-    int rc = FCPT_OK;
-    for (int k = 0; k < 4 && !rc; ++k)
-        rc = dev_alloc(c, &c->xbuf[k], (size_t)cnt);
-    if (!rc)
-        rc = dev_alloc(c, &c->d_cfl, 1);
-    if (rc)
-        return rc;
-    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->e_packed, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->e_received, hipEventDisableTiming));
-    return FCPT_OK;
+    if (int rc = comm_create_host(path, c->d.rank, c->d.nranks, (size_t)cnt, &c->comm))
+        return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
+    return comm_attach(c, false, c->d.rank);
+}
+
+int fcpt_comm_barrier(fcpt_ctx *c)
+{
+    if (!c)
+        return FCPT_EINVAL;
+    if (!c->comm) {
+        set_error("fcpt_comm_barrier needs fcpt_comm_init or fcpt_comm_init_host");
+        return FCPT_EINVAL;
+    }
+    join_side(c);
+    const int rc = comm_barrier(c->comm, c->stream);
+    return rc == FCPT_EHIP ? FCPT_ECOMM : rc;
 }
 
 int fcpt_comm_destroy(fcpt_ctx *c)

@@ -1,7 +1,14 @@
 // fargocpt_hip -- host driver over the C ABI: reads a FargoCPT YAML setup, runs the gas update
 // on the GPU with the reference's main loop and writes snapshots in the reference's format.
 //
-//   fargocpt_hip [-q] [-N <steps>] start <config.yml>
+//   fargocpt_hip [-q] [--lenient] [-N <steps>] [--ranks <n>] [--transport auto|rccl|host] start|auto|restart [N] <config.yml>
+//
+// --ranks n: the reference's `mpirun -np n fargocpt_exe ...` (src/parallel.cpp:28-40, one MPI rank per radial slab):
+// this process starts n copies of itself -- before anything touches a GPU -- one per slab and GPU, and waits for
+// them; the slabs exchange their ghost rings and the CFL minimum through the library (RCCL when every rank has a GPU
+// of its own, the host-staged transport otherwise, e.g. 2 or 3 ranks on a 1-GPU box) and write their windows of the
+// snapshot files as write2D does (src/polargrid.cpp:135-180).  A launcher of one's own sets FCPT_RANK, FCPT_NRANKS
+// and FCPT_RDV (a directory all ranks see) instead.
 //
 // Counterpart of src/main.cpp:47-164 + sim::run (src/simulation.cpp:505-558) +
 // handle_outputs (:50-98) for the gas path only.  N-body objects do not feel anything here
@@ -27,7 +34,11 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <fcntl.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -467,22 +478,69 @@ void mkdirs(const std::string &p)
         }                                                                                \
     } while (0)
 
-// write2D (src/polargrid.cpp:135-180): raw FP64, global row-major, single slab => whole grid
-void write_grid(fcpt_ctx *ctx, int field, size_t n, const std::string &path)
+// This process's slab: rank, the rows of the global grid it holds and the window of them it writes
+// (Zero_or_active / Max_or_active, src/split.cpp:66-78)
+struct Slab {
+    int rank = 0, nranks = 1;
+    fcpt_split s;
+    int nphi = 0, nr_global = 0;
+    bool master() const { return rank == 0; }
+    bool multi() const { return nranks > 1; }
+    size_t local_count(bool vec) const { return (size_t)(s.nr + (vec ? 1 : 0)) * nphi; }
+    // rows [lo, hi) of the local grid that write2D / write1D store, at global row imin + lo: the overlap rings are
+    // stripped, and only the last slab writes the last interface row of a vector grid (polargrid.cpp:150-172)
+    void window(bool vec, int &lo, int &hi) const
+    {
+        lo = s.zero_or_active;
+        hi = s.max_or_active + ((vec && s.is_last) ? 1 : 0);
+    }
+};
+Slab g_slab;
+fcpt_ctx *g_ctx = nullptr;
+
+void barrier()
 {
-    std::vector<double> buf(n);
-    CHECK(fcpt_download(ctx, field, buf.data()));
+    if (g_slab.multi())
+        CHECK(fcpt_comm_barrier(g_ctx));
+}
+
+bool is_vector_field(int field) { return field == FCPT_F_VRAD || field == FCPT_F_VRAD0 || field == FCPT_F_MASSFLOW; }
+
+// rank 0 creates / truncates the files of a collective write before the others open them
+void create_file(const std::string &path)
+{
     FILE *f = fopen(path.c_str(), "wb");
-    if (!f || fwrite(buf.data(), sizeof(double), n, f) != n) {
-        fprintf(stderr, "fargocpt_hip: cannot write %s\n", path.c_str());
+    if (!f) {
+        fprintf(stderr, "fargocpt_hip: cannot create %s\n", path.c_str());
         exit(1);
     }
     fclose(f);
 }
 
-// t_polargrid::read2D (src/polargrid.cpp:301-353): raw doubles, ring-major
-bool read_grid(fcpt_ctx *ctx, int field, size_t n, const std::string &path, bool required)
+// write2D (src/polargrid.cpp:135-180): raw FP64, global row-major; every slab writes its window at
+// (IMIN + Zero_or_active) * Nsec.  Collective: the file exists (create_file + barrier) before this is called.
+void write_grid(fcpt_ctx *ctx, int field, const std::string &path)
 {
+    const bool vec = is_vector_field(field);
+    std::vector<double> buf(g_slab.local_count(vec));
+    CHECK(fcpt_download(ctx, field, buf.data()));
+    int lo, hi;
+    g_slab.window(vec, lo, hi);
+    const int fd = open(path.c_str(), O_WRONLY);
+    const size_t nb = (size_t)(hi - lo) * g_slab.nphi * sizeof(double);
+    const off_t off = (off_t)(g_slab.s.imin + lo) * g_slab.nphi * sizeof(double);
+    if (fd < 0 || pwrite(fd, buf.data() + (size_t)lo * g_slab.nphi, nb, off) != (ssize_t)nb) {
+        fprintf(stderr, "fargocpt_hip: rank %d cannot write %s\n", g_slab.rank, path.c_str());
+        exit(1);
+    }
+    close(fd);
+}
+
+// t_polargrid::read2D (src/polargrid.cpp:301-353): raw doubles, ring-major; every slab takes its rows
+// IMIN .. IMIN + NRadial (overlap rings included) out of the global file
+bool read_grid(fcpt_ctx *ctx, int field, const std::string &path, bool required)
+{
+    const bool vec = is_vector_field(field);
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) {
         if (required) {
@@ -491,11 +549,19 @@ bool read_grid(fcpt_ctx *ctx, int field, size_t n, const std::string &path, bool
         }
         return false;
     }
+    const size_t n_global = (size_t)(g_slab.nr_global + (vec ? 1 : 0)) * g_slab.nphi, n = g_slab.local_count(vec);
+    fseek(f, 0, SEEK_END);
+    const size_t have = (size_t)ftell(f) / sizeof(double);
+    if (have != n_global) {
+        fprintf(stderr, "fargocpt_hip: %s holds %zu values, expected %zu (Nrad / Naz changed?)\n", path.c_str(), have, n_global);
+        exit(1);
+    }
     std::vector<double> buf(n);
+    fseek(f, (long)((size_t)g_slab.s.imin * g_slab.nphi * sizeof(double)), SEEK_SET);
     const size_t got = fread(buf.data(), sizeof(double), n, f);
     fclose(f);
     if (got != n) {
-        fprintf(stderr, "fargocpt_hip: %s holds %zu values, expected %zu (Nrad / Naz changed?)\n", path.c_str(), got, n);
+        fprintf(stderr, "fargocpt_hip: short read of %s\n", path.c_str());
         exit(1);
     }
     CHECK(fcpt_upload(ctx, field, buf.data()));
@@ -512,19 +578,99 @@ struct misc_entry { // src/output.h:16-24
     unsigned long int N_iter;
 };
 
+char **g_argv = nullptr;
+
+// The parent of `--ranks n`: starts n copies of this program, one per slab, before anything here has touched a GPU
+// (fork + exec at once), hands them FCPT_RANK / FCPT_NRANKS / FCPT_RDV (a fresh rendezvous directory under the output
+// directory: the RCCL id or the shared-memory file of the host-staged transport), and waits for all of them.  The
+// first rank that fails ends the others -- they would wait for it in a collective -- with SIGTERM to exactly the
+// children started here.
+int launch_ranks(int n, const std::string &outdir, bool quiet)
+{
+    mkdirs(outdir);
+    const std::string rdv = outdir + ".fcpt_rdv_" + std::to_string((long)getpid());
+    mkdir(rdv.c_str(), 0700);
+    std::vector<pid_t> pids((size_t)n, (pid_t)-1);
+    for (int r = 0; r < n; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) {
+            perror("fargocpt_hip: fork");
+            for (int k = 0; k < r; ++k)
+                kill(pids[k], SIGTERM);
+            return 1;
+        }
+        if (pid == 0) {
+            setenv("FCPT_RANK", std::to_string(r).c_str(), 1);
+            setenv("FCPT_NRANKS", std::to_string(n).c_str(), 1);
+            setenv("FCPT_RDV", rdv.c_str(), 1);
+            setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); // dmabuf IPC: what RCCL needs between processes on this driver
+            execv("/proc/self/exe", g_argv);
+            perror("fargocpt_hip: execv");
+            _exit(127);
+        }
+        pids[r] = pid;
+    }
+    int failed = 0, alive = n;
+    double t_term = 0.0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    while (alive > 0) {
+        bool progress = false;
+        for (int r = 0; r < n; ++r) {
+            if (pids[r] < 0)
+                continue;
+            int st = 0;
+            const pid_t w = waitpid(pids[r], &st, WNOHANG);
+            if (w != pids[r])
+                continue;
+            progress = true;
+            pids[r] = -1;
+            --alive;
+            const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+            if (rc != 0 && !failed) {
+                failed = rc;
+                fprintf(stderr, "fargocpt_hip: rank %d ended with code %d: ending the other ranks\n", r, rc);
+                for (int k = 0; k < n; ++k)
+                    if (pids[k] > 0)
+                        kill(pids[k], SIGTERM);
+                t_term = now();
+            }
+        }
+        if (failed && alive > 0 && now() - t_term > 10.0) {
+            for (int k = 0; k < n; ++k)
+                if (pids[k] > 0)
+                    kill(pids[k], SIGKILL);
+            t_term = now() + 1e9;
+        }
+        if (!progress)
+            usleep(2000);
+    }
+    for (const char *f : {"/rccl_id", "/rccl_id.tmp", "/hostlink"})
+        unlink((rdv + f).c_str());
+    rmdir(rdv.c_str());
+    if (!quiet && !failed)
+        printf("fargocpt_hip: %d ranks finished\n", n);
+    return failed ? 1 : 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv)
 {
+    g_argv = argv;
     bool quiet = false, lenient = false;
     long max_steps = -1, restart_from = -1;
-    std::string mode, cfgpath;
+    int want_ranks = 1;
+    std::string mode, cfgpath, transport = "auto";
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-q")
             quiet = true;
         else if (a == "--lenient")
             lenient = true;
+        else if ((a == "--ranks" || a == "-np") && i + 1 < argc)
+            want_ranks = atoi(argv[++i]);
+        else if (a == "--transport" && i + 1 < argc)
+            transport = lower(argv[++i]);
         else if (a == "-N" && i + 1 < argc)
             max_steps = atol(argv[++i]);
         else if (mode.empty())
@@ -535,10 +681,29 @@ int main(int argc, char **argv)
             cfgpath = a;
     }
     // start_mode.cpp:29-113: start | restart [N] | auto
-    if ((mode != "start" && mode != "restart" && mode != "auto") || cfgpath.empty()) {
-        fprintf(stderr, "usage: fargocpt_hip [-q] [-N steps] start|auto|restart [N] <config.yml>\n");
+    if ((mode != "start" && mode != "restart" && mode != "auto") || cfgpath.empty() || want_ranks < 1 ||
+        (transport != "auto" && transport != "rccl" && transport != "host")) {
+        fprintf(stderr, "usage: fargocpt_hip [-q] [--lenient] [-N steps] [--ranks n] [--transport auto|rccl|host] "
+                        "start|auto|restart [N] <config.yml>\n");
         return 2;
     }
+    // this process's rank: FCPT_RANK / FCPT_NRANKS from the --ranks parent below or from a launcher of the caller's
+    Slab &slab = g_slab;
+    const char *env_rank = getenv("FCPT_RANK"), *env_nranks = getenv("FCPT_NRANKS");
+    if (env_rank && env_nranks) {
+        slab.rank = atoi(env_rank);
+        slab.nranks = atoi(env_nranks);
+        if (slab.nranks < 1 || slab.rank < 0 || slab.rank >= slab.nranks) {
+            fprintf(stderr, "fargocpt_hip: FCPT_RANK=%s FCPT_NRANKS=%s\n", env_rank, env_nranks);
+            return 2;
+        }
+        if (want_ranks > 1 && want_ranks != slab.nranks) {
+            fprintf(stderr, "fargocpt_hip: --ranks %d but FCPT_NRANKS=%d\n", want_ranks, slab.nranks);
+            return 2;
+        }
+    }
+    if (slab.rank > 0)
+        quiet = true; // one voice, as logging::print_master
     Config cfg;
     if (!cfg.load(cfgpath)) {
         fprintf(stderr, "Can not find config file %s!\n", cfgpath.c_str());
@@ -549,6 +714,30 @@ int main(int argc, char **argv)
     std::string outdir = cfg.str("OutputDir", "output/out");
     if (outdir.back() != '/')
         outdir += "/";
+    { // config::Config::exit_on_unknown_key (src/config.cpp:119-138, called at src/main.cpp:111-113)
+        std::string unknown;
+        for (auto &kv : cfg.kv) {
+            bool known = false;
+            for (const char *k : kReferenceKeys)
+                known = known || kv.first == k;
+            if (!known)
+                unknown += (unknown.empty() ? "" : ", ") + kv.first;
+        }
+        if (!unknown.empty() && slab.rank == 0) {
+            fprintf(stderr, "%sUnknown key(s) found in config file: '%s'\nMaybe there is a typo?\n",
+                    lenient ? "fargocpt_hip: warning: " : "", unknown.c_str());
+        }
+        if (!unknown.empty() && !lenient)
+            return 1;
+        for (const char *k : kRefusedWhenOn)
+            if (cfg.has(k) && cfg.flag(k, false)) {
+                fprintf(stderr, "fargocpt_hip: '%s' is switched on, but that part of the reference is outside this driver's "
+                                "gas path\n", k);
+                return 2;
+            }
+    }
+    if (want_ranks > 1 && !(env_rank && env_nranks))
+        return launch_ranks(want_ranks, outdir, quiet); // the n ranks run, this process only waits for them
     // start_mode::configure_start_mode (src/start_mode.cpp:29-113): auto = restart from the last snapshot of
     // snapshots/list.txt if there is one; restart without a number likewise
     std::string restart_dir;
@@ -576,32 +765,6 @@ int main(int argc, char **argv)
         }
     }
     const bool restarting = mode == "restart";
-    { // config::Config::exit_on_unknown_key (src/config.cpp:119-138, called at src/main.cpp:111-113)
-        std::string unknown;
-        for (auto &kv : cfg.kv) {
-            bool known = false;
-            for (const char *k : kReferenceKeys)
-                known = known || kv.first == k;
-            if (!known)
-                unknown += (unknown.empty() ? "" : ", ") + kv.first;
-            else if (!quiet && !cfg.used.count(kv.first) && kv.first.compare(0, 5, "write") != 0 &&
-                     kv.first.compare(0, 8, "particle") != 0)
-                fprintf(stderr, "fargocpt_hip: note: key '%s' is not used by the gas path\n", kv.first.c_str());
-        }
-        if (!unknown.empty()) {
-            fprintf(stderr, "%sUnknown key(s) found in config file: '%s'\nMaybe there is a typo?\n",
-                    lenient ? "fargocpt_hip: warning: " : "", unknown.c_str());
-            if (!lenient)
-                return 1;
-        }
-        for (const char *k : kRefusedWhenOn)
-            if (cfg.has(k) && cfg.flag(k, false)) {
-                fprintf(stderr, "fargocpt_hip: '%s' is switched on, but that part of the reference is outside this driver's "
-                                "gas path\n", k);
-                return 2;
-            }
-    }
-
     // bodies: star + planets on fixed circular orbits
     std::vector<Body> bodies;
     for (size_t k = 0; k < cfg.nbody.size(); ++k) {
@@ -619,8 +782,13 @@ int main(int argc, char **argv)
 
     std::vector<double> radii(d.nr_global + FCPT_GEOM_PAD + 1);
     CHECK(fcpt_radii(&d, radii.data()));
+    // The initial fields of the GLOBAL grid (rank 0 of 1), of which every slab then takes its rows IMIN .. IMIN + NRadial:
+    // the reference fills each rank's rows from the same formulas of the global ring index, and the one global quantity
+    // of init_physics -- SetSigma0's disk mass, an MPI sum there -- is then the same number on every rank by construction
     const size_t ns = (size_t)d.nr_global * d.nphi, nv = (size_t)(d.nr_global + 1) * d.nphi;
     std::vector<double> sigma(ns), vrad(nv), vazi(ns), energy(ns);
+    d.rank = 0;
+    d.nranks = 1;
     CHECK(fcpt_initial_fields(&d, radii.data(), sigma.data(), vrad.data(), vazi.data(), energy.data()));
     // SigmaCondition / EnergyCondition: 2D (init.cpp:1002-1007,1307-1312: read2D of the named file); 1D needs the
     // reference's GSL spline and is not offered
@@ -647,12 +815,78 @@ int main(int argc, char **argv)
         }
         fclose(f);
     }
+    // ---- this rank's slab, its GPU and its communicator (SplitDomain, src/split.cpp:34-88; src/parallel.cpp:28-40) ------
+    d.rank = slab.rank;
+    d.nranks = slab.nranks;
+    CHECK(fcpt_split_domain(&d, &slab.s));
+    slab.nphi = d.nphi;
+    slab.nr_global = d.nr_global;
+    int32_t ndev = 0;
+    CHECK(fcpt_device_count(&ndev));
+    if (ndev <= 0) {
+        fprintf(stderr, "fargocpt_hip: no HIP device: the gas update has no CPU path\n");
+        return 1;
+    }
+    if (transport == "auto")
+        transport = slab.nranks <= ndev ? "rccl" : "host";
+    if (slab.multi() && transport == "rccl" && slab.nranks > ndev) {
+        fprintf(stderr, "fargocpt_hip: --transport rccl needs one GPU per rank (%d ranks, %d GPU(s)): RCCL refuses two "
+                        "ranks on one device\n", slab.nranks, (int)ndev);
+        return 2;
+    }
+    CHECK(fcpt_set_device(slab.rank % ndev));
     fcpt_ctx *ctx = nullptr;
     CHECK(fcpt_create(&d, radii.data(), &ctx));
-    CHECK(fcpt_upload(ctx, FCPT_F_SIGMA, sigma.data()));
-    CHECK(fcpt_upload(ctx, FCPT_F_VRAD, vrad.data()));
-    CHECK(fcpt_upload(ctx, FCPT_F_VAZI, vazi.data()));
-    CHECK(fcpt_upload(ctx, FCPT_F_ENERGY, energy.data()));
+    g_ctx = ctx;
+    {
+        const size_t row0 = (size_t)slab.s.imin * d.nphi; // local row 0 = global row IMIN
+        CHECK(fcpt_upload(ctx, FCPT_F_SIGMA, sigma.data() + row0));
+        CHECK(fcpt_upload(ctx, FCPT_F_VRAD, vrad.data() + row0));
+        CHECK(fcpt_upload(ctx, FCPT_F_VAZI, vazi.data() + row0));
+        CHECK(fcpt_upload(ctx, FCPT_F_ENERGY, energy.data() + row0));
+        for (std::vector<double> *v : {&sigma, &vrad, &vazi, &energy})
+            std::vector<double>().swap(*v); // the global copies are not needed any more
+    }
+    if (slab.multi()) {
+        const char *e = getenv("FCPT_RDV");
+        const std::string rdv = e && e[0] ? std::string(e) : outdir + ".fcpt_rdv";
+        if (slab.master())
+            mkdirs(rdv + "/");
+        if (transport == "host") {
+            CHECK(fcpt_comm_init_host(ctx, (rdv + "/hostlink").c_str()));
+        } else {
+            // ncclGetUniqueId on slab 0; the 128 bytes travel by file (the reference's host would MPI_Bcast them)
+            unsigned char id[FCPT_COMM_ID_BYTES];
+            const std::string idf = rdv + "/rccl_id";
+            if (slab.master()) {
+                CHECK(fcpt_comm_unique_id(id));
+                FILE *f = fopen((idf + ".tmp").c_str(), "wb");
+                if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id) || fclose(f) != 0 || rename((idf + ".tmp").c_str(), idf.c_str()) != 0) {
+                    fprintf(stderr, "fargocpt_hip: cannot write %s\n", idf.c_str());
+                    return 1;
+                }
+            } else {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {
+                    FILE *f = fopen(idf.c_str(), "rb");
+                    const bool ok = f && fread(id, 1, sizeof(id), f) == sizeof(id);
+                    if (f)
+                        fclose(f);
+                    if (ok)
+                        break;
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+                        fprintf(stderr, "fargocpt_hip: rank %d: no RCCL id in %s after 120 s\n", slab.rank, idf.c_str());
+                        return 1;
+                    }
+                    usleep(2000);
+                }
+            }
+            CHECK(fcpt_comm_init(ctx, id));
+        }
+        if (!quiet)
+            printf("fargocpt_hip: %d radial slabs, %s transport, %d GPU(s) visible\n", slab.nranks,
+                   transport == "host" ? "host-staged" : "RCCL", (int)ndev);
+    }
 
     // Bodies at time t for the potential of a step of length dt (CalculateNbodyPotential, Pframeforce.cpp:21-94):
     // positions on the circular orbits, masses ramped up (get_rampup_mass, planet.cpp:166-179), and the indirect term
@@ -701,15 +935,17 @@ int main(int argc, char **argv)
             ramp[k] = b.count("irradiation ramp-up time") ? number(b.at("irradiation ramp-up time"), K_NONE) : 0.0;
             any = any || temp[k] > 0.0;
         }
-        if (any)
+        if (any && d.eos == FCPT_EOS_IDEAL) // (without the energy equation a body's temperature heats nothing)
             CHECK(fcpt_set_body_irradiation(ctx, n, temp, rad, ramp));
     }
     CHECK(fcpt_init_physics(ctx));
 
     // ---- output files -------------------------------------------------------------------------
-    mkdirs(outdir + "snapshots/");
-    mkdirs(outdir + "monitor/");
-    if (!restarting) {
+    if (slab.master()) {
+        mkdirs(outdir + "snapshots/");
+        mkdirs(outdir + "monitor/");
+    }
+    if (!restarting && slab.master()) {
         FILE *f = fopen((outdir + "used_rad.dat").c_str(), "w"); // src/init.cpp:228-246
         for (int n = 0; n <= d.nr_global; ++n)
             fprintf(f, "%.18g\n", radii[n]);
@@ -796,40 +1032,58 @@ int main(int argc, char **argv)
         fcpt_clock clk;
         CHECK(fcpt_get_clock(ctx, &clk));
         const std::string dir = outdir + "snapshots/" + (name ? std::string(name) : std::to_string(nsnap)) + "/";
-        mkdirs(dir);
-        write_grid(ctx, FCPT_F_SIGMA, ns, dir + "Sigma.dat");
-        write_grid(ctx, FCPT_F_VRAD, nv, dir + "vrad.dat");
-        write_grid(ctx, FCPT_F_VAZI, ns, dir + "vazi.dat");
+        std::vector<std::pair<int, std::string>> grids = {{FCPT_F_SIGMA, "Sigma.dat"}, {FCPT_F_VRAD, "vrad.dat"}, {FCPT_F_VAZI, "vazi.dat"}};
         if (d.eos == FCPT_EOS_IDEAL) {
-            write_grid(ctx, FCPT_F_ENERGY, ns, dir + "energy.dat");
-            write_grid(ctx, FCPT_F_TEMPERATURE, ns, dir + "Temperature.dat");
+            grids.push_back({FCPT_F_ENERGY, "energy.dat"});
+            grids.push_back({FCPT_F_TEMPERATURE, "Temperature.dat"});
             // the CFL condition of the next step reads Q+ and Q- of the last one (cfl.cpp:303-316): restart.cpp:78-95
-            write_grid(ctx, FCPT_F_QPLUS, ns, dir + "Qplus.dat");
-            write_grid(ctx, FCPT_F_QMINUS, ns, dir + "Qminus.dat");
+            grids.push_back({FCPT_F_QPLUS, "Qplus.dat"});
+            grids.push_back({FCPT_F_QMINUS, "Qminus.dat"});
         }
-        if (d.write_massflow && !name) {
+        const bool massflow = d.write_massflow && !name;
+        // MPI_File_open(MPI_MODE_CREATE) is collective in the reference; here rank 0 creates the directory and the
+        // empty files, then every slab writes its window into them
+        if (slab.master()) {
+            mkdirs(dir);
+            for (auto &g : grids)
+                create_file(dir + g.second);
+            if (massflow)
+                create_file(dir + "MassFlow1D.dat");
+        }
+        barrier();
+        for (auto &g : grids)
+            write_grid(ctx, g.first, dir + g.second);
+        if (massflow) {
             // MassFlow1D.dat (t_polargrid::write1D, polargrid.cpp:187-278, of a vector grid that is integrated over
             // azimuth): pairs (Rinf[n], sum_j MASSFLOW(n, j) / (Nmonitor MonitorTimestep)) -- calculate_massflow,
-            // quantities.cpp:770-781 -- then the grid is cleared (data.cpp:277)
-            std::vector<double> mf(nv), out(2 * (size_t)(d.nr_global + 1));
+            // quantities.cpp:770-781 -- every slab its window of interfaces at (IMIN + Zero_or_active) * 2, then the
+            // grid is cleared (data.cpp:277)
+            std::vector<double> mf(slab.local_count(true));
             CHECK(fcpt_download(ctx, FCPT_F_MASSFLOW, mf.data()));
+            int lo, hi;
+            slab.window(true, lo, hi);
+            std::vector<double> out(2 * (size_t)(hi - lo));
             const double denom = (double)d.nmonitor * d.monitor_timestep;
-            for (int n = 0; n <= d.nr_global; ++n) {
+            for (int n = lo; n < hi; ++n) {
                 double sum = 0.0;
                 for (int j = 0; j < d.nphi; ++j)
                     sum += mf[(size_t)n * d.nphi + j] / denom;
-                out[2 * n] = radii[n];
-                out[2 * n + 1] = sum;
+                out[2 * (size_t)(n - lo)] = radii[slab.s.imin + n];
+                out[2 * (size_t)(n - lo) + 1] = sum;
             }
-            FILE *f1 = fopen((dir + "MassFlow1D.dat").c_str(), "wb");
-            if (!f1 || fwrite(out.data(), sizeof(double), out.size(), f1) != out.size()) {
+            const int fd = open((dir + "MassFlow1D.dat").c_str(), O_WRONLY);
+            const size_t nb = out.size() * sizeof(double);
+            if (fd < 0 || pwrite(fd, out.data(), nb, (off_t)(slab.s.imin + lo) * 2 * sizeof(double)) != (ssize_t)nb) {
                 fprintf(stderr, "fargocpt_hip: cannot write %sMassFlow1D.dat\n", dir.c_str());
                 exit(1);
             }
-            fclose(f1);
+            close(fd);
             std::fill(mf.begin(), mf.end(), 0.0);
             CHECK(fcpt_upload(ctx, FCPT_F_MASSFLOW, mf.data()));
         }
+        barrier(); // the grids are complete before misc.bin and list.txt announce the snapshot
+        if (!slab.master())
+            return;
         misc_entry misc;
         memset(&misc, 0, sizeof(misc));
         misc.timestep = nsnap;
@@ -859,12 +1113,24 @@ int main(int argc, char **argv)
             printf("Writing output %s, Snapshot Number %u, Time %f.\n", dir.c_str(), nsnap, clk.time);
     };
 
+    if (!quiet) // keys the reference knows and this driver's gas path does not consume
+        for (auto &kv : cfg.kv)
+            if (!cfg.used.count(kv.first) && kv.first.compare(0, 5, "write") != 0 && kv.first.compare(0, 8, "particle") != 0)
+                fprintf(stderr, "fargocpt_hip: note: key '%s' is not used by the gas path\n", kv.first.c_str());
+
     // ---- main.cpp:117-152 and sim::run (simulation.cpp:505-558) --------------------------------
-    auto calc_dt = [&]() {
+    auto calc_dt = [&]() { // condition_cfl incl. its MPI_Allreduce(MIN) over the slabs (cfl.cpp:379) + CalculateTimeStep
         double cfl, dt;
-        CHECK(fcpt_cfl(ctx, &cfl));
+        if (slab.multi())
+            CHECK(fcpt_cfl_allreduce(ctx, &cfl));
+        else
+            CHECK(fcpt_cfl(ctx, &cfl));
         CHECK(fcpt_calculate_timestep(ctx, cfl, &dt));
         return dt;
+    };
+    auto exchange = [&]() { // CommunicateBoundaries (commbound.cpp:98-182): returns at once for a single slab
+        if (slab.multi())
+            CHECK(fcpt_exchange(ctx));
     };
     calc_dt();          // main.cpp:117
     unsigned n_monitor = 0;
@@ -880,19 +1146,19 @@ int main(int argc, char **argv)
         fclose(mf);
         if (needs_reference) {
             const std::string ref = outdir + "snapshots/reference/";
-            read_grid(ctx, FCPT_F_SIGMA0, ns, ref + "Sigma.dat", true);
-            read_grid(ctx, FCPT_F_VRAD0, nv, ref + "vrad.dat", true);
-            read_grid(ctx, FCPT_F_VAZI0, ns, ref + "vazi.dat", true);
+            read_grid(ctx, FCPT_F_SIGMA0, ref + "Sigma.dat", true);
+            read_grid(ctx, FCPT_F_VRAD0, ref + "vrad.dat", true);
+            read_grid(ctx, FCPT_F_VAZI0, ref + "vazi.dat", true);
             if (d.eos == FCPT_EOS_IDEAL)
-                read_grid(ctx, FCPT_F_ENERGY0, ns, ref + "energy.dat", true);
+                read_grid(ctx, FCPT_F_ENERGY0, ref + "energy.dat", true);
         }
-        read_grid(ctx, FCPT_F_SIGMA, ns, restart_dir + "Sigma.dat", true);
-        read_grid(ctx, FCPT_F_VRAD, nv, restart_dir + "vrad.dat", true);
-        read_grid(ctx, FCPT_F_VAZI, ns, restart_dir + "vazi.dat", true);
+        read_grid(ctx, FCPT_F_SIGMA, restart_dir + "Sigma.dat", true);
+        read_grid(ctx, FCPT_F_VRAD, restart_dir + "vrad.dat", true);
+        read_grid(ctx, FCPT_F_VAZI, restart_dir + "vazi.dat", true);
         if (d.eos == FCPT_EOS_IDEAL) {
-            read_grid(ctx, FCPT_F_ENERGY, ns, restart_dir + "energy.dat", true);
-            const bool qp = read_grid(ctx, FCPT_F_QPLUS, ns, restart_dir + "Qplus.dat", false);
-            const bool qm = read_grid(ctx, FCPT_F_QMINUS, ns, restart_dir + "Qminus.dat", false);
+            read_grid(ctx, FCPT_F_ENERGY, restart_dir + "energy.dat", true);
+            const bool qp = read_grid(ctx, FCPT_F_QPLUS, restart_dir + "Qplus.dat", false);
+            const bool qm = read_grid(ctx, FCPT_F_QMINUS, restart_dir + "Qminus.dat", false);
             if (!(qp && qm) && !quiet)
                 printf("Cannot read Qplus / Qminus, no bitwise identical restarting possible!\n");
         }
@@ -912,16 +1178,18 @@ int main(int argc, char **argv)
         if (!quiet)
             printf("Restarting from %s at time %f (snapshot %u, monitor step %u).\n", restart_dir.c_str(), time,
                    misc.timestep, misc.nTimeStep);
-    } else {
-        write_snapshot(0, 0); // main.cpp:150-152
     }
-    CHECK(fcpt_apply_boundary(ctx, 0.0, 0)); // sim::init
+    exchange(); // CommunicateBoundariesAll, main.cpp:147
+    if (!restarting)
+        write_snapshot(0, 0); // main.cpp:150-152
+    CHECK(fcpt_apply_boundary(ctx, 0.0, 0)); // sim::init (simulation.cpp:462-474)
     if (!restarting)
         calc_dt();
+    exchange();
 
     const double t_final = (double)d.nsnapshots * d.nmonitor * d.monitor_timestep;
-    FILE *tlog = fopen((outdir + "monitor/timestepLogging.dat").c_str(), restarting ? "a" : "w");
-    if (!restarting)
+    FILE *tlog = slab.master() ? fopen((outdir + "monitor/timestepLogging.dat").c_str(), restarting ? "a" : "w") : nullptr;
+    if (tlog && !restarting)
         fprintf(tlog, "#version: 2\n#FargoCPT Time log for the hydro timestep size.\n"
                   "#variable: 0  | snapshot number | 1\n#variable: 1  | monitor number | 1\n"
                   "#variable: 2  | hydrostep number | 1\n#variable: 3  | Number of Hydrosteps in last monitor_timestep | 1\n"
@@ -979,6 +1247,7 @@ int main(int argc, char **argv)
         if (moving)
             set_bodies(time, step_dt);
         CHECK(fcpt_step(ctx, step_dt));
+        exchange(); // simulation.cpp:236
         CHECK(fcpt_post(ctx, step_dt));
         time += step_dt;
         ++n_iter;
@@ -995,9 +1264,11 @@ int main(int argc, char **argv)
             const unsigned long nint = n_iter - n_iter_last;
             CHECK(fcpt_dt_statistics(ctx, &min_dt, &max_dt, 1)); // hydro_dt_logger: kept next to the device clock
             const double ms = nint ? 1e3 * std::chrono::duration<double>(now - t_last).count() / nint : 0.0;
-            fprintf(tlog, "%u\t%u\t%lu\t%lu\t%#.16e\t%#.16e\t%#.16e\t%#.16e\t%#.16e\t%#.16e\n", clk.n_snapshot, n_monitor,
-                    n_iter, nint, time, wall, ms, nint ? sum_dt / nint : 0.0, min_dt, max_dt);
-            fflush(tlog);
+            if (tlog) {
+                fprintf(tlog, "%u\t%u\t%lu\t%lu\t%#.16e\t%#.16e\t%#.16e\t%#.16e\t%#.16e\t%#.16e\n", clk.n_snapshot,
+                        n_monitor, n_iter, nint, time, wall, ms, nint ? sum_dt / nint : 0.0, min_dt, max_dt);
+                fflush(tlog);
+            }
             t_last = now;
             n_iter_last = n_iter;
             sum_dt = 0;
@@ -1007,8 +1278,10 @@ int main(int argc, char **argv)
                 write_snapshot(n_monitor / (unsigned)d.nmonitor, n_monitor);
         }
     }
-    fclose(tlog);
+    if (tlog)
+        fclose(tlog);
     CHECK(fcpt_synchronize(ctx));
+    barrier(); // no slab tears its communicator down while another still waits in it
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (!quiet)
         printf("-- Final: Total Hydrosteps %lu, Time %.2f, Walltime %.2f seconds, Time per Step: %.2f milliseconds\n", n_iter,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FCPT_ABI_VERSION 4
+#define FCPT_ABI_VERSION 5
 
 /* error codes */
 #define FCPT_OK 0
@@ -282,6 +282,12 @@ const char *fcpt_last_error(void);
 
 /* ---- context ------------------------------------------------------------ */
 
+/* One process per GPU (the reference: one MPI rank per slab, src/parallel.cpp:28-40): the number of HIP devices this
+ * process sees (0 without a GPU; never fails) and the choice of the one the following fcpt_create uses.  Call
+ * fcpt_set_device before any other GPU-touching call of the process. */
+int fcpt_device_count(int32_t *n);
+int fcpt_set_device(int32_t device);
+
 /* Allocate all device state for slab d->rank on the current HIP device.
  * `radii` is the global interface array from fcpt_radii (or a radii.dat).
  * Replaces data.set_size + init_radialarrays + InitTransport + cfl::init
@@ -302,6 +308,8 @@ int fcpt_synchronize(fcpt_ctx *ctx);
  * source_rows, theta_rows, transport_fallback, transport_split, fused_source, march_source, march_source_adi,
  * theta_march, theta_fused, cfl_rings, cfl_split, source_ring_parts, fused_damping, inline_potential, cfl_thermal, bc_fold, comm_overlap,
  * comm_loopback, graph_steps, profile_stride (fcpt_profile_start times every n-th launch of the selected kernels).
+ * fcpt_get_option also answers three read-only counters of fcpt_run_steps: graph_replays (hipGraphLaunch calls issued
+ * so far), graph_cycle (steps per replay, 0 = no graph), coop_active (1: its steps run as one cooperative kernel each).
  * FCPT_EINVAL for an unknown name.  (The reference has no counterpart: its variants are compile-time.) */
 int fcpt_set_option(fcpt_ctx *ctx, const char *name, int32_t value);
 int fcpt_get_option(const fcpt_ctx *ctx, const char *name, int32_t *value);
@@ -454,6 +462,19 @@ int fcpt_exchange_unpack(fcpt_ctx *ctx, const double *recv_inner, const double *
 int fcpt_comm_unique_id(void *id128);
 int fcpt_comm_init(fcpt_ctx *ctx, const void *id128);
 int fcpt_comm_destroy(fcpt_ctx *ctx);
+
+/* The same communicator for ranks that cannot use RCCL among themselves -- several slabs on one GPU (RCCL refuses two
+ * ranks on one device), i.e. rehearsals and tests of the N-rank path on a 1-GPU box, or more slabs than devices:
+ * ghost rings and the CFL value are staged through pinned host memory and the shared-memory file `path` (collective
+ * over the d->nranks slabs of ONE node; slab 0 creates the file, which must not belong to another run, and removes it
+ * in fcpt_comm_destroy).  fcpt_exchange, fcpt_cfl_allreduce, fcpt_comm_barrier and fcpt_run_steps then work as with
+ * fcpt_comm_init, but block the host in every transfer.  FCPT_HOSTLINK_TIMEOUT (seconds, default 120) bounds every
+ * wait for another rank: FCPT_ECOMM afterwards. */
+int fcpt_comm_init_host(fcpt_ctx *ctx, const char *path);
+
+/* MPI_Barrier over the slabs of the communicator (src/main.cpp:141, the output routines): returns when every slab
+ * has called it; the work queued on this context's stream before the call is complete then. */
+int fcpt_comm_barrier(fcpt_ctx *ctx);
 
 /* CommunicateBoundaries (src/commbound.cpp:98-182) of this slab, whole: pack rows [7,14) / [nr-14,nr-7),
  * grouped send/recv with the neighbours, unpack into rows [0,7) / [nr-7,nr).  Asynchronous.  With the option

@@ -602,8 +602,8 @@ int orc_create(const fcpt_desc *d, const double *radii, orc_ctx **out)
         return FCPT_EINVAL;
     if (d->stabilize_viscosity < 0 || d->stabilize_viscosity > 2 || !d->body_force_from_potential)
         return FCPT_EINVAL;
-    if ((d->cooling_surface || d->cooling_beta) && d->eos != FCPT_EOS_IDEAL)
-        return FCPT_EINVAL;
+    /* (cooling switches of an isothermal setup are inert: SubStep3 is only called `if (parameters::Adiabatic)`,
+     * simulation.cpp:205-207) */
     if (d->cooling_surface && d->opacity != FCPT_OPACITY_LIN && d->opacity != FCPT_OPACITY_CONST &&
         d->opacity != FCPT_OPACITY_SIMPLE)
         return FCPT_EINVAL;

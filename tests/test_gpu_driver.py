@@ -328,3 +328,87 @@ def test_initial_state_from_2d_files(tmp_path):
     cfg3.write_text(DISK_YML.format(eos="Ideal", integrator="Euler", cooling="No", out=tmp_path / "c") + "SigmaCondition: 1D\n")
     r = subprocess.run([BIN, "-q", "start", str(cfg3)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "not supported" in r.stderr
+
+
+# ---- N ranks: the reference's `mpirun -np N fargocpt_exe start cfg.yml` ----------------------------------------------------
+def _run_ranks(tmp_path, setup, outname, ranks, extra=(), edits=None, mode=("start",)):
+    cfg = tmp_path / f"config_{outname}.yml"
+    out = tmp_path / outname
+    text = open(os.path.join(GOLDEN, "setups", setup)).read().splitlines()
+    text = [("OutputDir: " + str(out)) if l.startswith("OutputDir") else l for l in text]
+    for key, val in (edits or {}).items():
+        text = [(f"{key}: {val}") if l.split(":")[0].strip() == key else l for l in text]
+    cfg.write_text("\n".join(text) + "\n")
+    cmd = [BIN, "-q"] + (["--ranks", str(ranks)] if ranks > 1 else []) + list(extra) + list(mode) + [str(cfg)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert not [p for p in os.listdir(out) if p.startswith(".fcpt_rdv")], "rendezvous directory left behind"
+    return str(out) + "/"
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_n_rank_driver_matches_one_rank(tmp_path, ranks):
+    """test/mpi_simple (128 x 384, examples/config.yml physics: locally isothermal disk + Jupiter, alpha viscosity, TW
+    artificial viscosity, reflecting boundaries + damping) with `--ranks N`: N processes, one radial slab each, on the
+    one GPU of the test box -- so the ghost rings and the CFL minimum travel through the library's host-staged
+    transport (RCCL refuses two ranks on one device; with >= N GPUs the same command takes RCCL).  The reference's
+    criterion is that snapshots/1/misc.bin exists (test/mpi_simple/check_results.py:6-11); here the files every slab
+    wrote its window of (write2D, src/polargrid.cpp:135-180) must also equal the 1-process run's: same number of
+    steps, Sigma / vrad / vazi to <= 1e-12 of max|field| (the reference itself: 4e-13 between 1 and 2 MPI ranks,
+    BASELINE.md section 2)."""
+    one = _run_ranks(tmp_path, "mpi_simple.yml", "one", 1)
+    many = _run_ranks(tmp_path, "mpi_simple.yml", f"np{ranks}", ranks)
+    assert os.path.exists(many + "snapshots/1/misc.bin")          # the reference's criterion
+    m1, mn = _misc(one + "snapshots/1/misc.bin"), _misc(many + "snapshots/1/misc.bin")
+    assert mn["n_iter"] == m1["n_iter"] and mn["n_iter"] > 20
+    assert mn["time"] == pytest.approx(m1["time"], rel=1e-14) and mn["last_dt"] == pytest.approx(m1["last_dt"], rel=1e-10)
+    assert open(many + "snapshots/list.txt").read().split() == ["0", "1"]
+    assert np.array_equal(np.loadtxt(many + "used_rad.dat"), np.loadtxt(one + "used_rad.dat"))
+    for snap in ("0", "reference", "1"):
+        for name, rows in (("Sigma", 128), ("vrad", 129), ("vazi", 128)):
+            a = np.fromfile(many + f"snapshots/{snap}/{name}.dat")
+            b = np.fromfile(one + f"snapshots/{snap}/{name}.dat")
+            assert a.size == b.size == rows * 384, (snap, name)
+            if snap != "1":
+                assert np.array_equal(a, b), (snap, name)          # the initial state: the same bits
+            else:
+                assert _rel(a, b) <= 1e-12, (snap, name, _rel(a, b))
+                assert not np.array_equal(a, np.fromfile(one + f"snapshots/0/{name}.dat"))
+
+
+def test_n_rank_restart_and_ideal_eos(tmp_path):
+    """Two slabs with the energy equation (4 exchanged grids, Temperature / Qplus / Qminus windows) over two
+    snapshots, then `restart 1` with two slabs: read2D's per-slab rows (src/polargrid.cpp:301-353) and restart_load
+    (src/restart.cpp:18-139) reproduce the uninterrupted 2-slab run bit for bit, and both agree with one slab."""
+    edits = {"EquationOfState": "Ideal", "Nsnapshots": "2", "MonitorTimestep": "0.314", "SurfaceCooling": "No"}
+    one = _run_ranks(tmp_path, "mpi_simple.yml", "one", 1, edits=edits)
+    two = _run_ranks(tmp_path, "mpi_simple.yml", "two", 2, edits=edits)
+    names = ("Sigma", "vrad", "vazi", "energy", "Temperature", "Qplus", "Qminus")
+    for name in names:
+        a, b = np.fromfile(two + f"snapshots/2/{name}.dat"), np.fromfile(one + f"snapshots/2/{name}.dat")
+        assert a.size == b.size
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= (1e-12 if name not in ("Qplus", "Qminus") else 1e-9) * scale, name
+    full = {n: np.fromfile(two + f"snapshots/2/{n}.dat") for n in names}
+    import shutil
+    shutil.rmtree(two + "snapshots/2")
+    with open(two + "snapshots/list.txt", "w") as f:
+        f.write("0\n1\n")
+    again = _run_ranks(tmp_path, "mpi_simple.yml", "two", 2, edits=edits, mode=("restart", "1"))
+    assert _misc(again + "snapshots/2/misc.bin")["n_iter"] == _misc(one + "snapshots/2/misc.bin")["n_iter"]
+    for n in names:
+        assert np.array_equal(np.fromfile(again + f"snapshots/2/{n}.dat"), full[n]), n
+
+
+def test_unknown_key_is_fatal_as_in_the_reference(tmp_path):
+    """src/config.cpp:134-138: a key the reader does not know ends the run (a typo must not silently change the
+    physics); --lenient downgrades it to a warning."""
+    text = open(os.path.join(GOLDEN, "setups", "shocktube_SN.yml")).read()
+    cfg = tmp_path / "typo.yml"
+    cfg.write_text(text.replace("OutputDir", "OutputDir") + f"\nArtificalViscosity: TW\n")
+    r = subprocess.run([BIN, "-q", "start", str(cfg)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Unknown key(s) found in config file: 'artificalviscosity'" in r.stderr

@@ -212,3 +212,24 @@ def test_option_names_are_documented():
     assert not missing, missing
     for f in ("kernels/launch.h", "fcpt_step.hip", "fcpt_exchange.hip"):
         assert "getenv" not in open(os.path.join(ROOT, "fargocpt_amd", "csrc", f)).read(), f
+
+
+def test_rank_launcher_of_the_host_driver_reports_and_cleans_up(tmp_path):
+    """`fargocpt_hip --ranks 2` on a box without a GPU: both ranks stop with "no HIP device" (there is no CPU path),
+    the parent -- which started them before touching any GPU API -- reports the first failure, ends the other rank,
+    returns non-zero and leaves no rendezvous directory behind.  (With a GPU the same command runs: tests/test_gpu_driver.py.)"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the launcher is exercised by tests/test_gpu_driver.py")
+    exe = os.path.join(ROOT, "fargocpt_amd", "bin", "fargocpt_hip")
+    cfg = tmp_path / "c.yml"
+    cfg.write_text(f"Nrad: 64\nNaz: 64\nOutputDir: {tmp_path}/out\n")
+    r = subprocess.run([exe, "-q", "--ranks", "2", "start", str(cfg)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert "no HIP device" in r.stderr and "ending the other ranks" in r.stderr
+    assert not [p for p in os.listdir(tmp_path / "out") if p.startswith(".fcpt_rdv")]
+    # a key the reference's reader does not know is fatal before any rank starts (src/config.cpp:134-138)
+    cfg.write_text(f"Nrad: 64\nNazz: 64\nOutputDir: {tmp_path}/out\n")
+    r = subprocess.run([exe, "--ranks", "2", "start", str(cfg)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "Unknown key(s) found in config file: 'nazz'" in r.stderr and "no HIP device" not in r.stderr
