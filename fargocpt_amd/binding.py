@@ -30,8 +30,8 @@ DAMP_NONE, DAMP_REFERENCE, DAMP_ZERO, DAMP_MEAN = range(4)
 IC_PROFILE, IC_SPREADING_RING, IC_SHOCKTUBE = range(3)
 (F_SIGMA, F_VRAD, F_VAZI, F_ENERGY, F_PRESSURE, F_SOUNDSPEED, F_SCALE_HEIGHT, F_VISCOSITY,
  F_TEMPERATURE, F_POTENTIAL, F_SIGMA0, F_VRAD0, F_VAZI0, F_ENERGY0, F_QPLUS, F_QMINUS,
- F_VISC_CFAC_PHI, F_VISC_CFAC_R, F_MASSFLOW) = range(19)
-VECTOR_FIELDS = (F_VRAD, F_VRAD0, F_MASSFLOW)
+ F_VISC_CFAC_PHI, F_VISC_CFAC_R, F_MASSFLOW, F_ACCEL_RADIAL, F_ACCEL_AZIMUTHAL) = range(21)
+VECTOR_FIELDS = (F_VRAD, F_VRAD0, F_MASSFLOW, F_ACCEL_RADIAL, F_ACCEL_AZIMUTHAL)
 COMM_ID_BYTES = 128
 
 ERRORS = {-1: "FCPT_EINVAL", -2: "FCPT_ENOMEM", -3: "FCPT_EHIP", -4: "FCPT_ESPLIT", -5: "FCPT_ENODEV", -6: "FCPT_ESHEAR",
@@ -183,6 +183,13 @@ class Library:
 
     def set_device(self, device: int):
         self.check(self.fn("set_device")(_i32(device)), "set_device")
+
+    def selftest_half_limiter(self, limiter: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        a, b = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, b))
+        out = np.zeros_like(a)
+        self.check(self.fn("selftest_half_limiter")(_i32(limiter), C.c_int64(a.size), _as_dp(a), _as_dp(b), _as_dp(out)),
+                   "selftest_half_limiter")
+        return out
 
     def comm_unique_id(self) -> bytes:
         """ncclGetUniqueId: slab 0 calls it and hands the bytes to every slab (fcpt_comm_init)."""

@@ -152,13 +152,13 @@ void apply_options(fcpt_ctx *c, bool at_create = true)
         // intermediate fused ones: where the march does not run (narrow rings, switched off) fall back to the loops
         const bool march_runs = c->fused_source && c->march_source && c->P.nphi >= 128 &&
                                 (!c->P.adiabatic || o.march_source_adi != 0);
-        if (c->P.stabilize && !march_runs)
+        if ((c->P.stabilize || c->P.accel_force) && !march_runs) // (likewise BodyForceFromPotential: no)
             c->fused_source = c->march_source = false;
     }
     const bool adi_march =
         c->P.adiabatic && c->fused_source && c->march_source && c->P.nphi >= 128 && o.march_source_adi != 0;
     c->P.lazy_derived = adi_march ? 1 : 0;
-    c->P.inline_potential = (adi_march && !c->P.leapfrog && o.inline_potential != 0) ? 1 : 0;
+    c->P.inline_potential = (adi_march && !c->P.leapfrog && o.inline_potential != 0 && !c->P.accel_force) ? 1 : 0;
     // the transport leaves the cell-local CFL terms only where the CFL kernel that reads them will run (lazy derived
     // quantities, Euler: the leapfrog's second kick changes e after the transport)
     c->P.cfl_thermal = (adi_march && !c->P.leapfrog && o.cfl_thermal != 0) ? c->thermal_grid : nullptr;
@@ -231,13 +231,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         set_error("StabilizeViscosity must be 0, 1 or 2");
         return FCPT_EINVAL;
     }
-    if (!d->body_force_from_potential) {
-        set_error("BodyForceFromPotential: no is not supported");
-        return FCPT_EINVAL;
-    }
-    if (d->cooling_surface && d->opacity != FCPT_OPACITY_LIN && d->opacity != FCPT_OPACITY_CONST &&
-        d->opacity != FCPT_OPACITY_SIMPLE) {
-        set_error("Opacity: only Lin, Const and Simple are supported");
+    if (d->cooling_surface && d->eos == FCPT_EOS_IDEAL && (d->opacity < FCPT_OPACITY_LIN || d->opacity > FCPT_OPACITY_SIMPLE)) {
+        set_error("Opacity: Lin, Bell, Constant and Simple are the laws of the path (src/opacity.cpp:10-43)");
         return FCPT_EINVAL;
     }
     // the exponential spacing's Newton iteration (init.cpp:113-131) collapses to NaN for coarse grids
@@ -487,6 +482,10 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     if (d->write_massflow) {
         AL(massflow, nv)
     }
+    P.accel_force = d->body_force_from_potential ? 0 : 1;
+    if (P.accel_force) {
+        AL(accel_r, nv) AL(accel_az, nv) // zero-filled: rows 0 and nr are never written (Pframeforce.cpp:121-123)
+    }
     double *thermal_grid = nullptr; // ideal EOS: the cell-local CFL terms left by the marching transport
     if (!rc && d->eos == FCPT_EOS_IDEAL)
         rc = dev_alloc(c, &thermal_grid, ns);
@@ -524,6 +523,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     c->grid[FCPT_F_VISC_CFAC_PHI] = P.cfac_phi; // null unless StabilizeViscosity
     c->grid[FCPT_F_VISC_CFAC_R] = P.cfac_r;
     c->grid[FCPT_F_MASSFLOW] = P.massflow; // null unless WriteMassFlow
+    c->grid[FCPT_F_ACCEL_RADIAL] = P.accel_r; // null unless BodyForceFromPotential: no
+    c->grid[FCPT_F_ACCEL_AZIMUTHAL] = P.accel_az;
 
     P.zero_no_ghost = c->s.zero_no_ghost;
     P.one_no_ghost_vr = c->s.one_no_ghost_vr;
@@ -834,7 +835,8 @@ int fcpt_set_clock(fcpt_ctx *c, const fcpt_clock *in)
 
 static size_t grid_count(const fcpt_ctx *c, int32_t f)
 {
-    const bool vec = f == FCPT_F_VRAD || f == FCPT_F_VRAD0 || f == FCPT_F_MASSFLOW;
+    const bool vec = f == FCPT_F_VRAD || f == FCPT_F_VRAD0 || f == FCPT_F_MASSFLOW || f == FCPT_F_ACCEL_RADIAL ||
+                     f == FCPT_F_ACCEL_AZIMUTHAL;
     return (size_t)(c->s.nr + (vec ? 1 : 0)) * c->d.nphi;
 }
 
@@ -878,10 +880,12 @@ int fcpt_download(fcpt_ctx *c, int32_t f, double *host)
     if (f == FCPT_F_PRESSURE || (c->P.adiabatic && (f == FCPT_F_SOUNDSPEED || f == FCPT_F_SCALE_HEIGHT ||
                                                      f == FCPT_F_VISCOSITY || f == FCPT_F_TEMPERATURE)))
         ensure_pressure(c);
-    if (f == FCPT_F_POTENTIAL && !c->potential_valid) {
-        // evaluated inside the source march (ideal EOS): the grid on request, from the current state and bodies
+    if (f == FCPT_F_POTENTIAL && (!c->potential_valid || c->P.accel_force)) {
+        // evaluated inside the source march (ideal EOS), or not at all (BodyForceFromPotential: no): the grid on
+        // request, from the current state and bodies
         launch_potential(c->P, c->stream);
-        c->potential_valid = !c->P.adiabatic;
+        if (!c->P.accel_force) // (there the flag speaks for the acceleration grids)
+            c->potential_valid = !c->P.adiabatic;
     }
     HIPCHK(hipMemcpyAsync(host, c->grid[f], grid_count(c, f) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1042,6 +1046,35 @@ int fcpt_recalculate_derived(fcpt_ctx *c)
     }
     HIPCHK(hipGetLastError());
     return FCPT_OK;
+}
+
+// test hook: the transport kernels' half_limiter on host-supplied operands
+int fcpt_selftest_half_limiter(int32_t limiter, int64_t n, const double *a, const double *b, double *out)
+{
+    if (n < 0 || (n > 0 && (!a || !b || !out)) || (limiter != FCPT_LIMITER_VANLEER && limiter != FCPT_LIMITER_MC))
+        return FCPT_EINVAL;
+    if (n == 0)
+        return FCPT_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available");
+        return FCPT_ENODEV;
+    }
+    double *d = nullptr;
+    const size_t nb = (size_t)n * sizeof(double);
+    HIPCHK(hipMalloc((void **)&d, 3 * nb));
+    int rc = FCPT_OK;
+    if (hipMemcpy(d, a, nb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d + n, b, nb, hipMemcpyHostToDevice) != hipSuccess)
+        rc = FCPT_EHIP;
+    if (!rc) {
+        launch_selftest_half_limiter(limiter, n, d, d + n, d + 2 * n, nullptr);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d + 2 * n, nb, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = FCPT_EHIP;
+    }
+    (void)hipFree(d);
+    if (rc)
+        set_error("fcpt_selftest_half_limiter: a HIP call failed");
+    return rc;
 }
 
 int32_t fcpt_kernel_count(void) { return KID_COUNT; }

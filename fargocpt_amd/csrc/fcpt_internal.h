@@ -192,6 +192,10 @@ struct Dev {
     // StabilizeViscosity (viscosity.cpp:256-348): correction factors c1_phi, c1_r; null when it is 0
     double *cfac_phi, *cfac_r;
     double *massflow; // MASSFLOW (data.h:76), (nr+1) rows; null without WriteMassFlow
+    // BodyForceFromPotential: no -- ACCEL_RADIAL / ACCEL_AZIMUTHAL of CalculateAccelOnGas (Pframeforce.cpp:96-189),
+    // (nr+1) rows of which 1 .. nr-1 are written; null otherwise
+    double *accel_r, *accel_az;
+    int accel_force; // 1: the source step takes the bodies' pull from these grids, not from the potential's gradient
     CArr g_ra3;    // pow(Rinf[i], 3)
     int stabilize; // 0: off, 1: damp the viscous velocity update, 2: limit the time step
     // transport: momenta / density / energy, two sets (A: after pass 1, B: radial + final)

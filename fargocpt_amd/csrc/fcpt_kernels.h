@@ -20,7 +20,8 @@ enum KernelId {
     KID_SRC_FUSED, KID_AV_FUSED, KID_VISC_FUSED, KID_SOURCE_MARCH, KID_THETA_MARCH,
     KID_TRANSPORT_FUSED, KID_MASSFLOW, KID_CFL_RINGS, KID_TRANSPORT_FALLBACK, KID_EXCHANGE_COPY,
     KID_DISK_ON_BODY, KID_VISC_FACTORS, KID_SOURCE_MARCH_ADI, KID_SOURCE_MARCH_ADI_WIDE,
-    KID_TRANSPORT_FUSED_THERM, KID_TRANSPORT_FUSED_WIDE, KID_STEP_COOP, KID_COUNT
+    KID_TRANSPORT_FUSED_THERM, KID_TRANSPORT_FUSED_WIDE, KID_STEP_COOP, KID_ACCEL_ON_GAS,
+    KID_SOURCE_MARCH_ADI_ACC, KID_COUNT
 };
 static_assert(KID_COUNT <= 64, "fcpt_profile_start selects kernels with a 64-bit mask");
 extern const char *const kKernelNames[KID_COUNT];
@@ -39,6 +40,8 @@ struct Profiler {
 extern thread_local Profiler *g_prof;
 
 void launch_potential(const Dev &P, hipStream_t st);
+void launch_accel_on_gas(const Dev &P, hipStream_t st);
+void launch_body_force(const Dev &P, hipStream_t st); // the potential, or the accelerations (simulation.cpp:167-175)
 void launch_source(const Dev &P, hipStream_t st);
 void launch_artificial_viscosity(const Dev &P, hipStream_t st);
 void launch_recalculate_viscosity(const Dev &P, hipStream_t st);
@@ -49,6 +52,7 @@ void launch_visc_factors(const Dev &P, hipStream_t st);
 void launch_viscous_update(const Dev &P, hipStream_t st);
 void launch_substep3(const Dev &P, int update_energy, hipStream_t st);
 void launch_boundary(const Dev &P, hipStream_t st);
+void launch_selftest_half_limiter(int type, long long n, const double *a, const double *b, double *out, hipStream_t st);
 void launch_exchange_copy(const Dev &P, double *inner, double *outer, int unpack, hipStream_t st);
 void launch_damping(const Dev &P, double *q, double *q0, const double *radius, const DampRange &r,
                     int is_density, hipStream_t st);

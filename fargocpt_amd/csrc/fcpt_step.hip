@@ -93,7 +93,7 @@ void enqueue_potential(fcpt_ctx *c, bool midstep)
                 M.bm[k] = c->mm[k];
                 M.brsm[k] = c->mrsm[k];
             }
-        launch_potential(M, c->stream);
+        launch_body_force(M, c->stream);
         c->potential_valid = false;
         return;
     }
@@ -105,7 +105,7 @@ void enqueue_potential(fcpt_ctx *c, bool midstep)
             M.bm[k] = c->mm[k];
             M.brsm[k] = c->mrsm[k];
         }
-        launch_potential(M, c->stream);
+        launch_body_force(M, c->stream);
         c->potential_valid = false; // the grid now holds the mid-step potential
         return;
     }
@@ -114,7 +114,7 @@ void enqueue_potential(fcpt_ctx *c, bool midstep)
         return;
     }
     if (P.adiabatic || !c->potential_valid) {
-        launch_potential(P, c->stream); // CalculateNbodyPotential; static when H and the bodies are
+        launch_body_force(P, c->stream); // CalculateNbodyPotential | CalculateAccelOnGas; static when H and the bodies are
         c->potential_valid = true;
     }
 }

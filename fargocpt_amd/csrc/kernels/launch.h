@@ -12,7 +12,7 @@ const char *const kKernelNames[KID_COUNT] = {
     "k_cfl_cells", "k_clock", "k_src_fused", "k_av_fused", "k_visc_fused", "k_source_march",
     "k_transport_theta_march", "k_transport_fused", "k_massflow", "k_cfl_rings", "k_transport_fallback",
     "k_exchange_copy", "k_disk_on_body", "k_visc_factors", "k_source_march_adi", "k_source_march_adi_wide",
-    "k_transport_fused_therm", "k_transport_fused_wide", "k_step_coop"};
+    "k_transport_fused_therm", "k_transport_fused_wide", "k_step_coop", "k_accel_on_gas", "k_source_march_adi_acc"};
 
 thread_local Profiler *g_prof = nullptr;
 
@@ -68,6 +68,14 @@ void Profiler::end(int id, hipStream_t st)
     } while (0)
 
 void launch_potential(const Dev &P, hipStream_t st) { LAUNCH2D(KID_POTENTIAL, k_potential, P.nr, P); }
+void launch_accel_on_gas(const Dev &P, hipStream_t st) { LAUNCH2D(KID_ACCEL_ON_GAS, k_accel_on_gas, P.nr - 1, P); }
+void launch_body_force(const Dev &P, hipStream_t st)
+{
+    if (P.accel_force)
+        launch_accel_on_gas(P, st);
+    else
+        launch_potential(P, st);
+}
 
 void launch_source(const Dev &P, hipStream_t st)
 {
@@ -147,7 +155,7 @@ static int source_rows(const Dev &P)
     const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
     // wavefronts per SIMD of the instantiation that will run: 6 (isothermal), 4 (with StabilizeViscosity; ideal
     // EOS), 2 (ideal EOS with cooling terms or StabilizeViscosity)
-    const bool wide_adi = P.adiabatic && (P.stabilize || P.cooling_surface || P.cooling_beta || P.heating_star);
+    const bool wide_adi = P.adiabatic && (P.stabilize || P.cooling_surface || P.cooling_beta || P.heating_star || P.accel_force);
     const int occ = P.adiabatic ? (wide_adi ? 2 : 4) : (P.stabilize ? 4 : 6);
     const long slots = (long)device_cus() * 4 * occ;
     int r = 4;
@@ -243,11 +251,22 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
     } else {                                                                                                \
         KLAUNCH(KID_SOURCE_MARCH_ADI, (k_source_march_adi<AV_, POT_>), grid, block, P, segs, rows, ring_sums, bc_fold); \
     }
-#define ADIK(AV_)            \
-    if (P.inline_potential) { \
-        ADIKP(AV_, true);    \
-    } else {                 \
-        ADIKP(AV_, false);   \
+#define ADIKA(AV_, COOL_)                                                                                                  \
+    if (P.stabilize)                                                                                                       \
+        KLAUNCH(KID_SOURCE_MARCH_ADI_ACC, (k_source_march_adi_acc<AV_, COOL_, true>), grid, block, P, segs, rows, ring_sums, bc_fold); \
+    else                                                                                                                   \
+        KLAUNCH(KID_SOURCE_MARCH_ADI_ACC, (k_source_march_adi_acc<AV_, COOL_, false>), grid, block, P, segs, rows, ring_sums, bc_fold)
+#define ADIK(AV_)                 \
+    if (P.accel_force) {          \
+        if (cool) {               \
+            ADIKA(AV_, true);     \
+        } else {                  \
+            ADIKA(AV_, false);    \
+        }                         \
+    } else if (P.inline_potential) { \
+        ADIKP(AV_, true);         \
+    } else {                      \
+        ADIKP(AV_, false);        \
     }
         if (P.art_visc == FCPT_ARTVISC_TW) {
             ADIK(1);
@@ -257,6 +276,7 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
             ADIK(0);
         }
 #undef ADIK
+#undef ADIKA
 #undef ADIKP
 #undef ADIKS
         return ring_sums ? segs : -segs; // < 0: marched, but no ring sums
@@ -270,11 +290,17 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
     const int chunks = (P.nr + 1 + rows - 1) / rows;
     const int waves = segs * chunks;
     const dim3 grid((waves + 3) / 4), block(256);
-#define ISOK(AV_)                                                                                     \
-    if (P.stabilize)                                                                                  \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, true>), grid, block, P, segs, rows, ring_sums, bc_fold); \
-    else                                                                                              \
-        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, false>), grid, block, P, segs, rows, ring_sums, bc_fold)
+#define ISOKA(AV_, ACC_)                                                                                    \
+    if (P.stabilize)                                                                                        \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, true, ACC_>), grid, block, P, segs, rows, ring_sums, bc_fold); \
+    else                                                                                                    \
+        KLAUNCH(KID_SOURCE_MARCH, (k_source_march<AV_, false, ACC_>), grid, block, P, segs, rows, ring_sums, bc_fold)
+#define ISOK(AV_)          \
+    if (P.accel_force) {   \
+        ISOKA(AV_, true);  \
+    } else {               \
+        ISOKA(AV_, false); \
+    }
     if (P.art_visc == FCPT_ARTVISC_TW) {
         ISOK(1);
     } else if (P.art_visc == FCPT_ARTVISC_SN) {
@@ -283,6 +309,7 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
         ISOK(0);
     }
 #undef ISOK
+#undef ISOKA
     return ring_sums ? segs : -segs; // < 0: marched, but no ring sums
 }
 void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_FUSED, k_visc_fused, P.nr + 1, P); }
@@ -346,6 +373,11 @@ void launch_exchange_copy(const Dev &P, double *inner, double *outer, int unpack
     int bx = (int)((npair + 255) / 256);
     bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
     KLAUNCH(KID_EXCHANGE_COPY, k_exchange_copy, dim3(bx, 2 * a.nq), dim3(256), a);
+}
+
+void launch_selftest_half_limiter(int type, long long n, const double *a, const double *b, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_selftest_half_limiter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, type, n, a, b, out);
 }
 
 void launch_boundary(const Dev &P, hipStream_t st)

@@ -38,6 +38,44 @@ template <bool ROWU> __global__ void k_potential(const Dev P)
     P.potential[IDX(i, j)] = pot;
 }
 
+// Pframeforce.cpp:96-189 CalculateAccelOnGas (BodyForceFromPotential: no): rows 1 .. Nr-1 of ACCEL_RADIAL / ACCEL_AZIMUTHAL,
+// the operations in the reference's order (the one source kernel without fast reciprocals: sqrt and an IEEE division)
+template <bool ROWU> __global__ void k_accel_on_gas(const Dev P)
+{
+    CELL(1, P.nr - 1);
+    const double r = P.Rmed[i];
+    const double x = P.Rmed[i] * P.cosphi[j];
+    const double y = P.Rmed[i] * P.sinphi[j];
+    double H;
+    if (P.adiabatic && P.lazy_derived) { // k_adi_cs_h in registers
+        const double cs = sqrt(P.gamma * (P.gamma - 1.0) * P.energy[IDX(i, j)] * fast_rcp(P.sigma[IDX(i, j)]));
+        H = cs * (1.0 / sqrt(P.gamma)) * P.g_inv_omk[i];
+    } else {
+        H = P.scale_height[IDX(i, j)];
+    }
+    const double smooth = P.thickness_smoothing * H;
+    double ax = P.indirect_x, ay = P.indirect_y;
+    for (int k = 0; k < P.nbodies; ++k) {
+        const double dx = x - P.bx[k];
+        const double dy = y - P.by[k];
+        const double dist_2 = dx * dx + dy * dy;
+        const double dist_2_sm = dist_2 + smooth * smooth;
+        const double dist_sm = sqrt(dist_2_sm);
+        const double dist_3_sm = dist_sm * dist_2_sm;
+        const double inv_dist_3_sm = 1.0 / dist_3_sm;
+        double klahr = 1.0;
+        const double r_sm = P.brsm[k];
+        if (r_sm > 0.0 && dist_sm < r_sm) {
+            const double q = dist_sm / r_sm;
+            klahr = -(3.0 * ((q * q) * (q * q)) - 4.0 * (q * q * q));
+        }
+        ax -= dx * P.G * P.bm[k] * inv_dist_3_sm * klahr;
+        ay -= dy * P.G * P.bm[k] * inv_dist_3_sm * klahr;
+    }
+    P.accel_r[IDX(i, j)] = (x * ax + y * ay) / r;
+    P.accel_az[IDX(i, j)] = (x * ay - y * ax) / r;
+}
+
 // SourceEuler.cpp:325-372 momentum_update_radial
 template <bool ROWU> __global__ void k_source_vr(const Dev P)
 {
@@ -47,7 +85,8 @@ template <bool ROWU> __global__ void k_source_vr(const Dev P)
     double gradp = 2.0 / (P.sigma[IDX(i, j)] + P.sigma[IDX(i - 1, j)]);
     gradp *= (P.pressure[IDX(i, j)] - P.pressure[IDX(i - 1, j)]);
     gradp *= P.InvDiffRmed[i];
-    const double gradphi = (P.potential[IDX(i, j)] - P.potential[IDX(i - 1, j)]) * P.InvDiffRmed[i];
+    const double gradphi = P.accel_force ? -(P.accel_r[IDX(i, j)] + P.accel_r[IDX(i - 1, j)]) * 0.5 // :348-353
+                                         : (P.potential[IDX(i, j)] - P.potential[IDX(i - 1, j)]) * P.InvDiffRmed[i];
     const double vsum =
         P.vazi[IDX(i, j)] + P.vazi[IDX(i, jn)] + P.vazi[IDX(i - 1, j)] + P.vazi[IDX(i - 1, jn)];
     const double vt = 0.25 * vsum + P.Rinf[i] * P.omega_frame;
@@ -65,7 +104,8 @@ template <bool ROWU> __global__ void k_source_va(const Dev P)
     const double invdxtheta = 2.0 / (P.dphi * (P.Rsup[i] + P.Rinf[i]));
     const double gradp = 2.0 / (P.sigma[IDX(i, j)] + P.sigma[IDX(i, jp)]) *
                          (P.pressure[IDX(i, j)] - P.pressure[IDX(i, jp)]) * invdxtheta;
-    const double gradphi = (P.potential[IDX(i, j)] - P.potential[IDX(i, jp)]) * invdxtheta;
+    const double gradphi = P.accel_force ? -(P.accel_az[IDX(i, j)] + P.accel_az[IDX(i, jp)]) * 0.5 // :406-411
+                                         : (P.potential[IDX(i, j)] - P.potential[IDX(i, jp)]) * invdxtheta;
     P.vazi[IDX(i, j)] = P.vazi[IDX(i, j)] + dt * (-gradp - gradphi);
 }
 
@@ -467,6 +507,56 @@ __device__ double opacity_lin(double density, double temperature)
         return pow(pow(o1an * o2an / (o1an + o2an), 2.0) + pow(o3 / (1 + 1.e22 / t10), 4.0), 0.25);
     }
 }
+// opacity.cpp:170-297 bell(): Bell & Lin (1994), eight regions smoothed across their borders; cgs in / cgs out
+__device__ double opacity_bell(double density, double temperature)
+{
+    const double power1 = 2.8369e-2, power2 = 1.1464e-2, power3 = 2.2667e-1;
+    const double t234 = 1.46e3, t456 = 4.51e3, t678 = 2.37e6;
+    const double ak1 = 2.e-4, ak2 = 2.e16, ak3 = 0.1e0;
+    const double bk3 = 10., bk4 = 2.e-15, bk5 = 1e4, bk6 = 1e4, bk7 = 1.5e10, bk8 = 0.348;
+    if (temperature < 1.0)
+        temperature = 10.0;
+    if (temperature > t234 * pow(density, power1)) {
+        const double ts4 = 1.e-4 * temperature; // to avoid overflow
+        const double density13 = pow(density, 1.0 / 3.0);
+        const double density23 = density13 * density13;
+        const double ts42 = ts4 * ts4;
+        const double ts44 = ts42 * ts42;
+        const double ts48 = ts44 * ts44;
+        if (temperature > t456 * pow(density, power2)) {
+            if ((temperature < t678 * pow(density, power3)) || ((density <= 1e10) && (temperature < 1e4))) {
+                const double o5 = bk5 * density23 * ts42 * ts4;
+                const double o6 = bk6 * density13 * ts48 * ts42;
+                const double o7 = bk7 * density / (ts42 * sqrt(ts4));
+                const double o6an = o6 * o6, o7an = o7 * o7;
+                return pow(pow(o6an * o7an / (o6an + o7an), 2.0) +
+                               pow(o5 / (1.0 + pow(ts4 / (1.1 * pow(density, 0.04762)), 10.0)), 4.0),
+                           0.25);
+            } else {
+                const double o7 = bk7 * density / (ts42 * sqrt(ts4));
+                const double o8 = bk8;
+                const double o7an = o7 * o7, o8an = o8 * o8;
+                return pow(o7an * o7an + o8an * o8an, 0.25);
+            }
+        } else {
+            const double o3 = bk3 * sqrt(ts4);
+            const double o4 = bk4 * density / (ts48 * ts48 * ts48);
+            const double o5 = bk5 * density23 * ts42 * ts4;
+            const double o4an = pow(o4, 4.0), o3an = pow(o3, 4.0);
+            return pow((o4an * o3an / (o4an + o3an)) + pow(o5 / (1.0 + 6.561e-5 / ts48 * 1e2 * density23), 4.0), 0.25);
+        }
+    } else {
+        const double t2 = temperature * temperature;
+        const double t4 = t2 * t2;
+        const double t8 = t4 * t4;
+        const double t10 = t8 * t2;
+        const double o1 = ak1 * t2;
+        const double o2 = ak2 * temperature / t8;
+        const double o3 = ak3 * sqrt(temperature);
+        const double o1an = o1 * o1, o2an = o2 * o2;
+        return pow(pow(o1an * o2an / (o1an + o2an), 2.0) + pow(o3 / (1 + 1.e22 / t10), 4.0), 0.25);
+    }
+}
 // midplane_density + kappa_eff at one cell (compute.cpp:17-87): the effective optical depth
 __device__ __forceinline__ double tau_eff_of(const Dev &P, double sigma, double H, double temperature)
 {
@@ -475,6 +565,8 @@ __device__ __forceinline__ double tau_eff_of(const Dev &P, double sigma, double 
     double kappa;
     if (P.opacity == FCPT_OPACITY_LIN)
         kappa = opacity_lin(rho * P.density_cgs, temperatureCGS) * (1.0 / P.opacity_cgs);
+    else if (P.opacity == FCPT_OPACITY_BELL)
+        kappa = opacity_bell(rho * P.density_cgs, temperatureCGS) * (1.0 / P.opacity_cgs);
     else if (P.opacity == FCPT_OPACITY_CONST)
         kappa = P.kappa_const;
     else

@@ -59,7 +59,9 @@ __device__ __forceinline__ double visc_corr_march(double dt, double c) { return 
 
 // STAB: StabilizeViscosity 1 | 2 -- the correction factors are formed in stage E and stored (the CFL condition of
 // mode 2 and fcpt_download read the grids), mode 1 also damps the viscous velocity update with them.
-template <int AV, bool STAB> // AV 0: none, 1: TW, 2: SN
+// ACC: BodyForceFromPotential: no -- the window carries ACCEL_RADIAL (in the potential's place) and ACCEL_AZIMUTHAL of
+// CalculateAccelOnGas instead of the potential (SourceEuler.cpp:348-353, 406-411)
+template <int AV, bool STAB, bool ACC = false> // AV 0: none, 1: TW, 2: SN
 #ifdef SM_TRACE /* profiles/tools/wave_trace.py: the wavefronts' end times, at the production occupancy */
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 #else
@@ -88,7 +90,9 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
 
     // rolling state (suffix _1.._3 = rings m-1..m-3)
     double S_m = 0, S_1 = 0, S_2 = 0, S_3 = 0, Sp_m = 0, Sp_1 = 0, Sp_2 = 0; // Sigma and Sigma(j-1)
-    double F_m = 0, F_1 = 0;                                               // potential
+    double F_m = 0, F_1 = 0;                                               // potential (ACC: radial acceleration)
+    const double *const fgrid = ACC ? P.accel_r : P.potential;
+    double G_m = 0;                                                        // ACC: azimuthal acceleration
     double va0_m = 0, va0_1 = 0, va0n_m = 0, va0n_1 = 0;                   // v_phi (input) and (j+1)
     double vr1_m = 0, vr1_1 = 0, va1_m = 0, va1_1 = 0;                      // after source terms
     double qr_1 = 0, qr_2 = 0, qp_1 = 0, qp_2 = 0;                          // Q_rr/Q_pp (TW) or q_r/q_phi (SN)
@@ -101,14 +105,15 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
     {
         const int r = crow(k0 - 3);
         S_m = P.sigma[IDX(r, j)];
-        F_m = P.potential[IDX(r, j)];
+        F_m = fgrid[IDX(r, j)];
         va0_m = P.vazi[IDX(r, j)];
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
     }
     // software prefetch of the next input ring
     int rn = k0 - 2;
-    double pS = P.sigma[IDX(crow(rn), j)], pF = P.potential[IDX(crow(rn), j)];
+    double pS = P.sigma[IDX(crow(rn), j)], pF = fgrid[IDX(crow(rn), j)];
+    double pG = ACC ? P.accel_az[IDX(crow(rn), j)] : 0.0;
     double pVa = P.vazi[IDX(crow(rn), j)], pVr = P.vrad[IDX(vrow(rn), j)];
 
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
@@ -119,17 +124,21 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
         va0_1 = va0_m; va0n_1 = va0n_m;
         vr1_1 = vr1_m; va1_1 = va1_m;
         S_m = pS; F_m = pF; va0_m = pVa;
+        if (ACC)
+            G_m = pG;
         const double vr0_m = pVr;
         {
             const int r = m + 1;
             pS = P.sigma[IDX(crow(r), j)];
-            pF = P.potential[IDX(crow(r), j)];
+            pF = fgrid[IDX(crow(r), j)];
+            if (ACC)
+                pG = P.accel_az[IDX(crow(r), j)];
             pVa = P.vazi[IDX(crow(r), j)];
             pVr = P.vrad[IDX(vrow(r), j)];
         }
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
-        const double Fp_m = PREV(F_m);
+        const double Fp_m = ACC ? PREV(G_m) : PREV(F_m);
 
         // ---- A: source terms on ring m ---------------------------------------------------
         {
@@ -140,7 +149,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                 double gradp = 2.0 * fast_rcp(S_m + S_1);
                 gradp *= (P_m - P_1);
                 gradp *= R.idr_m;
-                const double gradphi = (F_m - F_1) * R.idr_m;
+                const double gradphi = ACC ? -(F_m + F_1) * 0.5 : (F_m - F_1) * R.idr_m;
                 const double vsum = va0_m + va0n_m + va0_1 + va0n_1;
                 const double vt = 0.25 * vsum + R.rinf_om_m;
                 const double vt2 = vt * vt;
@@ -150,7 +159,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
             if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
                 const double invdxtheta = R.inv_dxt_m; // 2 / (dphi (Rsup + Rinf))
                 const double gradp = 2.0 * fast_rcp(S_m + Sp_m) * (P_m - Pp_m) * invdxtheta;
-                const double gradphi = (F_m - Fp_m) * invdxtheta;
+                const double gradphi = ACC ? -(G_m + Fp_m) * 0.5 : (F_m - Fp_m) * invdxtheta;
                 va1_m = va0_m + dt * (-gradp - gradphi);
             }
         }
@@ -320,7 +329,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
 // POT: the potential of ring m is evaluated here (CalculateNbodyPotential, Pframeforce.cpp:21-94, with the
 // smoothing length ThicknessSmoothing * H of the cell, Force.cpp:124-159) instead of read from the grid
 // k_potential would have to refresh every step, because H follows the energy.
-template <int AV, bool COOL, bool POT, bool STAB> // AV 0: none, 1: TW, 2: SN
+template <int AV, bool COOL, bool POT, bool STAB, bool ACC = false> // AV 0: none, 1: TW, 2: SN; ACC: see k_source_march
 __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 {
     const int lane = threadIdx.x & 63;
@@ -348,8 +357,11 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
     auto vrow = [nr](int r) { return r < 0 ? 0 : (r > nr ? nr : r); };           // v_r rows
 
     // rolling state (suffix _1.._3 = rings m-1..m-3)
+    static_assert(!(ACC && POT), "the inline potential is the potential's path");
     double S_m = 0, S_1 = 0, S_2 = 0, S_3 = 0, Sp_m = 0; // Sigma and Sigma(j-1)
-    double F_m = 0, F_1 = 0;                                               // potential
+    double F_m = 0, F_1 = 0;                                               // potential (ACC: radial acceleration)
+    const double *const fgrid = ACC ? P.accel_r : P.potential;
+    double G_m = 0;                                                        // ACC: azimuthal acceleration
     // (register diet, 142 -> 128 VGPRs = 4 wavefronts per SIMD: the pressure (gamma - 1) e, Sigma(j-1) and nu(j-1)
     //  of ring m-2, v_phi(j+1) of ring m-1 and this lane's cos / sin are re-formed where they are used instead of
     //  carried in the rolling window -- the same values, bit for bit)
@@ -402,13 +414,14 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
         S_m = P.sigma[IDX(r, j)];
         va0_m = P.vazi[IDX(r, j)];
         e0_m = P.energy[IDX(r, j)];
-        F_m = POT ? potential_of(r, S_m, e0_m) : P.potential[IDX(r, j)];
+        F_m = POT ? potential_of(r, S_m, e0_m) : fgrid[IDX(r, j)];
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
     }
     // software prefetch of the next input ring
     int rn = k0 - 2;
-    double pS = P.sigma[IDX(crow(rn), j)], pF = POT ? 0.0 : P.potential[IDX(crow(rn), j)], pE = P.energy[IDX(crow(rn), j)];
+    double pS = P.sigma[IDX(crow(rn), j)], pF = POT ? 0.0 : fgrid[IDX(crow(rn), j)], pE = P.energy[IDX(crow(rn), j)];
+    double pG = ACC ? P.accel_az[IDX(crow(rn), j)] : 0.0;
     double pVa = P.vazi[IDX(crow(rn), j)], pVr = P.vrad[IDX(vrow(rn), j)];
 
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
@@ -428,12 +441,16 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
         e2_2 = e2_1; nu_2 = nu_1; H_2 = H_1;
         const double nup_2 = PREV(nu_2);
         S_m = pS; F_m = pF; va0_m = pVa; e0_m = pE;
+        if (ACC)
+            G_m = pG;
         const double vr0_m = pVr;
         {
             const int r = m + 1;
             pS = P.sigma[IDX(crow(r), j)];
             if (!POT)
-                pF = P.potential[IDX(crow(r), j)];
+                pF = fgrid[IDX(crow(r), j)];
+            if (ACC)
+                pG = P.accel_az[IDX(crow(r), j)];
             pE = P.energy[IDX(crow(r), j)];
             pVa = P.vazi[IDX(crow(r), j)];
             pVr = P.vrad[IDX(vrow(r), j)];
@@ -446,7 +463,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
         rp_m = fast_rcp(S_m + Sp_m);
         va0n_m = NEXT(va0_m);
         const double va0n_1 = NEXT(va0_1);
-        const double Fp_m = PREV(F_m);
+        const double Fp_m = ACC ? PREV(G_m) : PREV(F_m);
         const double Prp_m = PREV(Pr_m);
 
         // ---- A: source terms on ring m ---------------------------------------------------
@@ -457,7 +474,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                 double gradp = 2.0 * rr_m;
                 gradp *= (Pr_m - Pr_1);
                 gradp *= R.idr_m;
-                const double gradphi = (F_m - F_1) * R.idr_m;
+                const double gradphi = ACC ? -(F_m + F_1) * 0.5 : (F_m - F_1) * R.idr_m;
                 const double vsum = va0_m + va0n_m + va0_1 + va0n_1;
                 const double vt = 0.25 * vsum + R.rinf_om_m;
                 const double vt2 = vt * vt;
@@ -467,7 +484,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
             if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
                 const double invdxtheta = R.inv_dxt_m; // 2 / (dphi (Rsup + Rinf))
                 const double gradp = 2.0 * rp_m * (Pr_m - Prp_m) * invdxtheta;
-                const double gradphi = (F_m - Fp_m) * invdxtheta;
+                const double gradphi = ACC ? -(G_m + Fp_m) * 0.5 : (F_m - Fp_m) * invdxtheta;
                 va1_m = va0_m + dt * (-gradp - gradphi);
             }
         }
@@ -685,4 +702,11 @@ template <int AV, bool COOL, bool POT, bool STAB>
 __global__ void __launch_bounds__(256) k_source_march_adi_wide(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 {
     source_march_adi_body<AV, COOL, POT, STAB>(P, segs, rows_per_chunk, ring_sums, bc_fold);
+}
+// BodyForceFromPotential: no (never the default: one instantiation per artificial viscosity, cooling and
+// StabilizeViscosity decided at run time inside would cost the registers of the widest case, so they stay template flags)
+template <int AV, bool COOL, bool STAB>
+__global__ void __launch_bounds__(256) k_source_march_adi_acc(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
+{
+    source_march_adi_body<AV, COOL, false, STAB, true>(P, segs, rows_per_chunk, ring_sums, bc_fold);
 }

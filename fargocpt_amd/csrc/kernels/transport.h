@@ -489,13 +489,24 @@ __device__ __forceinline__ double half_limiter(int type, double a, double b)
     if (type == FCPT_LIMITER_MC)
         return 0.5 * limiter(type, a, b);
     // ab > 0 ? ab / (a + b) : 0 without the compare and the two selects: max(ab, 0) is the numerator, and the
-    // reciprocal is kept finite where a + b = 0 (then ab <= 0 and the product is an exact 0; a + b is +0, never -0:
-    // differences x - x round to +0).  For ab > 0 the operations are those of the select form, bit for bit.
+    // reciprocal is kept finite where it is not needed.  For ab > 0 the operations are those of the select form, bit
+    // for bit.  Where a + b is +-0 or a denormal, v_rcp_f64 returns +-inf and the Newton step NaN; the clamp BEHIND
+    // the Newton step turns that (v_min_f64 returns its non-NaN operand, as the compare-and-select it is written as)
+    // and every reciprocal beyond 1e300 into 1e300 -- reached only where |a|, |b| < 1e-300, i.e. where ab has
+    // underflowed to 0 or is <= 0 and the numerator is an exact 0 (round 2 clamped before the Newton step, which let a
+    // NEGATIVE denormal sum through as -inf -> NaN: ADVICE round 2).
     const double ab = a * b, d = a + b;
     double x = __builtin_amdgcn_rcp(d);
-    x = x < 1e300 ? x : 1e300; // v_min_f64
     x = fma(x, fma(-d, x, 1.0), x);
+    x = x < 1e300 ? x : 1e300; // v_min_f64; NaN -> 1e300
     return (ab > 0.0 ? ab : 0.0) * x; // v_max_f64
+}
+// fcpt_selftest_half_limiter: the device function on host-supplied operands
+__global__ void k_selftest_half_limiter(int type, long long n, const double *a, const double *b, double *out)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n)
+        out[k] = half_limiter(type, a[k], b[k]);
 }
 
 // Upwind star states of one quantity on the C cells of a lane (compute_star_theta,

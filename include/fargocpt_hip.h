@@ -96,7 +96,12 @@ enum {
      * Nmonitor * MonitorTimestep (quantities::calculate_massflow, src/quantities.cpp:770-781), sums over azimuth
      * for MassFlow1D.dat and clears the grid by uploading zeros (clear_after_write, src/data.cpp:277). */
     FCPT_F_MASSFLOW = 18,
-    FCPT_F_COUNT = 19
+    /* ACCEL_RADIAL / ACCEL_AZIMUTHAL (src/data.cpp:49-58), (Nr+1) x Nphi, only with BodyForceFromPotential: no: the
+     * cell-centred acceleration of the gas by the bodies and the indirect term that CalculateAccelOnGas
+     * (src/Pframeforce.cpp:96-189) left for the last source step (rows 0 and Nr are never written: zero) */
+    FCPT_F_ACCEL_RADIAL = 19,
+    FCPT_F_ACCEL_AZIMUTHAL = 20,
+    FCPT_F_COUNT = 21
 };
 
 /*
@@ -163,7 +168,8 @@ typedef struct fcpt_desc {
     /* frame + gravity */
     double omega_frame;                /* OmegaFrame */
     double thickness_smoothing;        /* ThicknessSmoothing */
-    int32_t body_force_from_potential; /* BodyForceFromPotential: only 1 is supported */
+    int32_t body_force_from_potential; /* BodyForceFromPotential: 1 = gradient of the potential (CalculateNbodyPotential),
+                                        * 0 = CalculateAccelOnGas (src/Pframeforce.cpp:96-189, SourceEuler.cpp:348-353,406-411) */
     int32_t _pad3;
     double hydro_center_mass; /* mass of the bodies defining the hydro centre */
 
@@ -199,7 +205,7 @@ typedef struct fcpt_desc {
 
     /* cooling terms of SubStep3 (calculate_qminus, src/SourceEuler.cpp:931-950; ideal EOS only) */
     int32_t cooling_surface; /* SurfaceCooling: thermal (src/SourceEuler.cpp:790-820) */
-    int32_t opacity;         /* Opacity (src/opacity.cpp): FCPT_OPACITY_*; Bell is not supported */
+    int32_t opacity;         /* Opacity (src/opacity.cpp:10-43): FCPT_OPACITY_* (Lin :45-168, Bell :170-297, Constant, Simple) */
     double cooling_radiative_factor; /* CoolingRadiativeFactor */
     double kappa_const;              /* KappaConst (code units: L0^2 / M0) */
     double kappa_factor;             /* KappaFactor */
@@ -519,6 +525,12 @@ int32_t fcpt_kernel_count(void);
 const char *fcpt_kernel_name(int32_t id);
 int fcpt_profile_start(fcpt_ctx *ctx, uint64_t mask, int32_t max_launches);
 int fcpt_profile_stop(fcpt_ctx *ctx, double *ms_total, int64_t *launches);
+
+/* Test hook: out[k] = 0.5 * flux_limiter(a[k], b[k]) (src/TransportEuler.cpp:306-337; limiter = FCPT_LIMITER_*) exactly
+ * as the transport kernels evaluate it on the device -- the van Leer form there is branch-free (max(ab, 0) times a
+ * guarded reciprocal of a + b) and its edge cases (+-0, denormal and cancelling sums) are what this call lets a test
+ * compare with `ab > 0 ? ab / (a + b) : 0`.  Host arrays of n doubles; blocks. */
+int fcpt_selftest_half_limiter(int32_t limiter, int64_t n, const double *a, const double *b, double *out);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ struct orc_ctx {
     /* state grids (data.h) */
     double *sigma, *vrad, *vazi, *energy;
     double *pressure, *soundspeed, *scale_height, *viscosity, *temperature, *potential;
+    double *accel_r, *accel_az; /* ACCEL_RADIAL, ACCEL_AZIMUTHAL (data.cpp:49-58), (Nr+1) x Nphi */
     double *sigma0, *vrad0, *vazi0, *energy0;
     double *qr, *qphi, *divv, *trr, *tpp, *trp /* vector */, *qplus, *qminus, *density_int;
     double *nusig, *nusig_rp /* vector */, *cfac_phi, *cfac_r; /* StabilizeViscosity (viscosity.cpp:256-348) */
@@ -600,12 +601,11 @@ int orc_create(const fcpt_desc *d, const double *radii, orc_ctx **out)
         return FCPT_EINVAL;
     if (d->struct_size != sizeof(fcpt_desc) || d->abi_version != FCPT_ABI_VERSION)
         return FCPT_EINVAL;
-    if (d->stabilize_viscosity < 0 || d->stabilize_viscosity > 2 || !d->body_force_from_potential)
+    if (d->stabilize_viscosity < 0 || d->stabilize_viscosity > 2)
         return FCPT_EINVAL;
     /* (cooling switches of an isothermal setup are inert: SubStep3 is only called `if (parameters::Adiabatic)`,
      * simulation.cpp:205-207) */
-    if (d->cooling_surface && d->opacity != FCPT_OPACITY_LIN && d->opacity != FCPT_OPACITY_CONST &&
-        d->opacity != FCPT_OPACITY_SIMPLE)
+    if (d->cooling_surface && (d->opacity < FCPT_OPACITY_LIN || d->opacity > FCPT_OPACITY_SIMPLE))
         return FCPT_EINVAL;
     /* the interfaces must be finite and strictly increasing (the exponential spacing's Newton iteration,
      * init.cpp:113-131, collapses to NaN for coarse grids) */
@@ -654,6 +654,8 @@ int orc_create(const fcpt_desc *d, const double *radii, orc_ctx **out)
     c->viscosity = dalloc(ns);
     c->temperature = dalloc(ns);
     c->potential = dalloc(ns);
+    c->accel_r = dalloc(nv);
+    c->accel_az = dalloc(nv);
     c->sigma0 = dalloc(ns);
     c->vrad0 = dalloc(nv);
     c->vazi0 = dalloc(ns);
@@ -712,7 +714,8 @@ int orc_destroy(orc_ctx *c)
                      &c->trp,        &c->qplus,     &c->qminus,      &c->density_int, &c->tau_eff, &c->nusig, &c->nusig_rp, &c->cfac_phi, &c->cfac_r,
                      &c->rmp,        &c->rmm,       &c->lp,          &c->lm,          &c->vres,
                      &c->vmean,      &c->work,      &c->qrstar,      &c->densstar,    &c->tempshift,
-                     &c->dq,         &c->cfl_vmean, &c->cfl_vres,    &c->massflow};
+                     &c->dq,         &c->cfl_vmean, &c->cfl_vres,    &c->massflow,
+                     &c->accel_r,    &c->accel_az};
     for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]); ++i)
         free(*ps[i]);
     free(c->nshift);
@@ -758,6 +761,8 @@ static double *field_ptr(orc_ctx *c, int32_t f, size_t *n)
     case FCPT_F_VISCOSITY: return c->viscosity;
     case FCPT_F_TEMPERATURE: return c->temperature;
     case FCPT_F_POTENTIAL: return c->potential;
+    case FCPT_F_ACCEL_RADIAL: *n = nv; return c->d.body_force_from_potential ? NULL : c->accel_r;
+    case FCPT_F_ACCEL_AZIMUTHAL: *n = nv; return c->d.body_force_from_potential ? NULL : c->accel_az;
     case FCPT_F_SIGMA0: return c->sigma0;
     case FCPT_F_VRAD0: *n = nv; return c->vrad0;
     case FCPT_F_VAZI0: return c->vazi0;
@@ -1040,6 +1045,52 @@ static void calculate_potential(orc_ctx *c)
         }
 }
 
+/* Pframeforce.cpp:96-189 CalculateAccelOnGas (BodyForceFromPotential: no): the bodies' pull and the indirect term as
+ * cell-centred accelerations; ACCEL_RADIAL / ACCEL_AZIMUTHAL are vector grids of Nr+1 rows of which rows 1 .. Nr-1 are
+ * written (rows 0 and Nr stay at their initial zero) */
+static void calculate_accel_on_gas(orc_ctx *c)
+{
+    const int Nr = c->nr, Nphi = c->nphi;
+#pragma omp parallel for if (c->big)
+    for (int nr = 1; nr < Nr; ++nr)
+        for (int naz = 0; naz < Nphi; ++naz) {
+            const double r = c->Rmed[nr];
+            const double x = c->Rmed[nr] * cos(c->dphi * (double)naz);
+            const double y = c->Rmed[nr] * sin(c->dphi * (double)naz);
+            double ax = c->indirect_x, ay = c->indirect_y;
+            for (int k = 0; k < c->nbodies; ++k) {
+                const double smooth = c->d.thickness_smoothing * c->scale_height[IDX(c, nr, naz)];
+                const double dx = x - c->bx[k];
+                const double dy = y - c->by[k];
+                const double dist_2 = dx * dx + dy * dy;
+                const double dist_2_sm = dist_2 + smooth * smooth;
+                const double dist_sm = sqrt(dist_2_sm);
+                const double dist_3_sm = dist_sm * dist_2_sm;
+                const double inv_dist_3_sm = 1.0 / dist_3_sm;
+                double smooth_factor_klahr = 1.0;
+                if (c->brsm[k] > 0.0) {
+                    const double r_sm = c->brsm[k];
+                    if (dist_sm < r_sm) {
+                        const double q = dist_sm / r_sm;
+                        smooth_factor_klahr = -(3.0 * ((q * q) * (q * q)) - 4.0 * (q * q * q));
+                    }
+                }
+                ax -= dx * c->d.G * c->bm[k] * inv_dist_3_sm * smooth_factor_klahr;
+                ay -= dy * c->d.G * c->bm[k] * inv_dist_3_sm * smooth_factor_klahr;
+            }
+            c->accel_r[IDX(c, nr, naz)] = (x * ax + y * ay) / r;
+            c->accel_az[IDX(c, nr, naz)] = (x * ay - y * ax) / r;
+        }
+}
+/* simulation.cpp:167-175: the potential, or the accelerations */
+static void calculate_body_force(orc_ctx *c)
+{
+    if (c->d.body_force_from_potential)
+        calculate_potential(c);
+    else
+        calculate_accel_on_gas(c);
+}
+
 /* ------------------------------------------------------------------------ */
 /* boundary conditions                                                       */
 
@@ -1307,7 +1358,9 @@ static void momentum_update_radial(orc_ctx *c, double dt)
             gradp *= (c->pressure[IDX(c, nr, naz)] - c->pressure[IDX(c, nr - 1, naz)]);
             gradp *= c->InvDiffRmed[nr];
             const double gradphi =
-                (c->potential[IDX(c, nr, naz)] - c->potential[IDX(c, nr - 1, naz)]) * c->InvDiffRmed[nr];
+                c->d.body_force_from_potential
+                    ? (c->potential[IDX(c, nr, naz)] - c->potential[IDX(c, nr - 1, naz)]) * c->InvDiffRmed[nr]
+                    : -(c->accel_r[IDX(c, nr, naz)] + c->accel_r[IDX(c, nr - 1, naz)]) * 0.5; /* :348-353 */
             const int naz_next = (naz == Nphi - 1 ? 0 : naz + 1);
             const double vsum = c->vazi[IDX(c, nr, naz)] + c->vazi[IDX(c, nr, naz_next)] +
                                 c->vazi[IDX(c, nr - 1, naz)] + c->vazi[IDX(c, nr - 1, naz_next)];
@@ -1330,7 +1383,9 @@ static void momentum_update_azimuthal(orc_ctx *c, double dt)
                                  (c->pressure[IDX(c, nr, naz)] - c->pressure[IDX(c, nr, naz_prev)]) *
                                  invdxtheta;
             const double gradphi =
-                (c->potential[IDX(c, nr, naz)] - c->potential[IDX(c, nr, naz_prev)]) * invdxtheta;
+                c->d.body_force_from_potential
+                    ? (c->potential[IDX(c, nr, naz)] - c->potential[IDX(c, nr, naz_prev)]) * invdxtheta
+                    : -(c->accel_az[IDX(c, nr, naz)] + c->accel_az[IDX(c, nr, naz_prev)]) * 0.5; /* :406-411 */
             c->vazi[IDX(c, nr, naz)] = c->vazi[IDX(c, nr, naz)] + dt * (-gradp - gradphi);
         }
     }
@@ -1678,6 +1733,56 @@ static double opacity_lin(double density, double temperature)
         return pow(pow(o1an * o2an / (o1an + o2an), 2) + pow(o3 / (1 + 1.e22 / t10), 4), 0.25);
     }
 }
+/* opacity.cpp:170-297 bell(): Bell & Lin (1994) opacities in eight regions, smoothed across their borders; cgs in / cgs out */
+static double opacity_bell(double density, double temperature)
+{
+    const double power1 = 2.8369e-2, power2 = 1.1464e-2, power3 = 2.2667e-1;
+    const double t234 = 1.46e3, t456 = 4.51e3, t678 = 2.37e6;
+    const double ak1 = 2.e-4, ak2 = 2.e16, ak3 = 0.1e0;
+    const double bk3 = 10., bk4 = 2.e-15, bk5 = 1e4, bk6 = 1e4, bk7 = 1.5e10, bk8 = 0.348;
+    if (temperature < 1.0)
+        temperature = 10.0;
+    if (temperature > t234 * pow(density, power1)) {
+        const double ts4 = 1.e-4 * temperature; /* to avoid overflow */
+        const double density13 = pow(density, 1.0 / 3.0);
+        const double density23 = density13 * density13;
+        const double ts42 = ts4 * ts4;
+        const double ts44 = ts42 * ts42;
+        const double ts48 = ts44 * ts44;
+        if (temperature > t456 * pow(density, power2)) {
+            if ((temperature < t678 * pow(density, power3)) || ((density <= 1e10) && (temperature < 1e4))) {
+                const double o5 = bk5 * density23 * ts42 * ts4;
+                const double o6 = bk6 * density13 * ts48 * ts42;
+                const double o7 = bk7 * density / (ts42 * sqrt(ts4));
+                const double o6an = o6 * o6, o7an = o7 * o7;
+                return pow(pow(o6an * o7an / (o6an + o7an), 2.0) +
+                               pow(o5 / (1.0 + pow(ts4 / (1.1 * pow(density, 0.04762)), 10.0)), 4.0),
+                           0.25);
+            } else {
+                const double o7 = bk7 * density / (ts42 * sqrt(ts4));
+                const double o8 = bk8;
+                const double o7an = o7 * o7, o8an = o8 * o8;
+                return pow(o7an * o7an + o8an * o8an, 0.25);
+            }
+        } else {
+            const double o3 = bk3 * sqrt(ts4);
+            const double o4 = bk4 * density / (ts48 * ts48 * ts48);
+            const double o5 = bk5 * density23 * ts42 * ts4;
+            const double o4an = pow(o4, 4.0), o3an = pow(o3, 4.0);
+            return pow((o4an * o3an / (o4an + o3an)) + pow(o5 / (1.0 + 6.561e-5 / ts48 * 1e2 * density23), 4.0), 0.25);
+        }
+    } else {
+        const double t2 = temperature * temperature;
+        const double t4 = t2 * t2;
+        const double t8 = t4 * t4;
+        const double t10 = t8 * t2;
+        const double o1 = ak1 * t2;
+        const double o2 = ak2 * temperature / t8;
+        const double o3 = ak3 * sqrt(temperature);
+        const double o1an = o1 * o1, o2an = o2 * o2;
+        return pow(pow(o1an * o2an / (o1an + o2an), 2.0) + pow(o3 / (1 + 1.e22 / t10), 4.0), 0.25);
+    }
+}
 /* opacity.cpp:10-43 opacity(): code units in / code units out */
 static double opacity_of(const fcpt_desc *d, double density, double temperature)
 {
@@ -1686,6 +1791,7 @@ static double opacity_of(const fcpt_desc *d, double density, double temperature)
     double rv;
     switch (d->opacity) {
     case FCPT_OPACITY_LIN: rv = opacity_lin(densityCGS, temperatureCGS) * (1.0 / d->opacity_cgs); break;
+    case FCPT_OPACITY_BELL: rv = opacity_bell(densityCGS, temperatureCGS) * (1.0 / d->opacity_cgs); break;
     case FCPT_OPACITY_CONST: rv = d->kappa_const; break;
     case FCPT_OPACITY_SIMPLE: rv = d->kappa_const * (temperatureCGS * temperatureCGS); break;
     default: rv = 0.0; break;
@@ -2371,7 +2477,7 @@ int orc_step(orc_ctx *c, double dt)
         return FCPT_EINVAL;
     if (c->d.integrator == FCPT_INTEGRATOR_LEAPFROG) {
         const double frog_dt = dt / 2;
-        calculate_potential(c);
+        calculate_body_force(c);
         gas_kick(c, c->clk.time, frog_dt); /* start_time (simulation.cpp:333) */
         apply_boundary_condition(c, 0.0, 0);
         Transport(c, dt);
@@ -2381,16 +2487,16 @@ int orc_step(orc_ctx *c, double dt)
             memcpy(sm, c->bm, sizeof sm); memcpy(sr, c->brsm, sizeof sr);
             memcpy(c->bx, c->mx, sizeof sx); memcpy(c->by, c->my, sizeof sy);
             memcpy(c->bm, c->mm, sizeof sm); memcpy(c->brsm, c->mrsm, sizeof sr);
-            calculate_potential(c);
+            calculate_body_force(c);
             memcpy(c->bx, sx, sizeof sx); memcpy(c->by, sy, sizeof sy);
             memcpy(c->bm, sm, sizeof sm); memcpy(c->brsm, sr, sizeof sr);
         } else {
-            calculate_potential(c);
+            calculate_body_force(c);
         }
         compute_pressure(c);
         gas_kick(c, c->clk.time + frog_dt, frog_dt); /* midstep_time (simulation.cpp:388) */
     } else {
-        calculate_potential(c);
+        calculate_body_force(c);
         gas_kick(c, c->clk.time, dt);
         apply_boundary_condition(c, 0.0, 0);
         Transport(c, dt);

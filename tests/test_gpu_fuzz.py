@@ -91,6 +91,10 @@ def draw(lib, seed):
         # irradiation_single (SourceEuler.cpp:538-612): a hot star and a warm planet with a ramp-up time
         _EXTRA["irradiation"] = ([pick(4000.0, 10000.0) / setups.TEMP0_K, pick(0.0, 1500.0) / setups.TEMP0_K],
                                  [4.65e-3, 4.8e-4], [0.0, pick(0.0, 0.01)])
+    # appended draw (round 3): BodyForceFromPotential: no -- CalculateAccelOnGas instead of the potential's gradient
+    # (Pframeforce.cpp:96-189), in every source path (marching, per-loop) and integrator
+    if rng.integers(5) == 0:
+        d.body_force_from_potential = 0
     return d, nslabs, planet
 
 

@@ -696,3 +696,94 @@ def test_cfl_thermal_option(product, oracle, nslabs, monkeypatch):
     monkeypatch.setenv("FCPT_CFL_THERMAL", "1")
     d = setups.planet_disk(product, 80, 320, adiabatic=True)
     _check(run_pair(product, oracle, d, 25, bodies=setups.jupiter_bodies(d), nslabs=(nslabs, 1)), ("sigma", "vrad", "vazi", "energy"))
+
+
+@pytest.mark.parametrize("case", ["iso_march_64x320", "iso_loops_48x64", "ideal_march_48x288_cubic", "ideal_cooling_40x256",
+                                  "leapfrog_40x192", "stab_two_slabs_64x256", "ideal_loops_32x96"])
+def test_body_force_from_accelerations(product, oracle, case):
+    """BodyForceFromPotential: no: CalculateAccelOnGas (Pframeforce.cpp:96-189) fills
+    ACCEL_RADIAL / ACCEL_AZIMUTHAL and the source step takes -(a(i) + a(i-1)) / 2 and -(a(j) + a(j-1)) / 2 instead of
+    the potential's gradient (SourceEuler.cpp:348-353, 406-411) -- in the marching kernels (a template flag), in the
+    per-loop kernels of narrow rings, with the planet's cubic smoothing, the energy equation, leapfrog (mid-step
+    bodies) and radial slabs.  The state after N steps and the acceleration grids themselves against the oracle."""
+    from fargocpt_amd import driver
+    adi = case.startswith("ideal")
+    dims = [t for t in case.split("_") if "x" in t and t[0].isdigit()][0]
+    nr, nphi = (int(x) for x in dims.split("x"))
+    d = setups.planet_disk(product, nr, nphi, adiabatic=adi)
+    d.body_force_from_potential = 0
+    bodies = list(setups.jupiter_bodies(d))
+    fields = ("sigma", "vrad", "vazi") + (("energy",) if adi else ())
+    nslabs = (1, 1)
+    if "cubic" in case:       # Klahr & Kley smoothing inside the Hill radius (the derivative form of it) + an indirect term
+        x, y, m = bodies[0], bodies[1], bodies[2]
+        bodies = [x, y, m, [0.0, (m[1] / 3.0) ** (1.0 / 3.0)], (1.0e-4, -2.0e-4)]
+    if "cooling" in case:
+        d.cooling_surface, d.opacity, d.kappa_const = 1, B.OPACITY_CONST, 1.0e4
+    if "leapfrog" in case:
+        d.integrator = B.INTEGRATOR_LEAPFROG
+    if "stab" in case:
+        d.stabilize_viscosity = 1
+        nslabs = (2, 1)
+    _check(run_pair(product, oracle, d, 20, bodies=tuple(bodies), nslabs=nslabs), fields)
+    # the grids CalculateAccelOnGas leaves behind, cell by cell (rows 0 and Nr stay zero)
+    radii = product.radii(d)
+    got = []
+    for lib in (product, oracle):
+        ctx = driver.make_context(lib, d, radii=radii, bodies=tuple(bodies))
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        S.run(2)
+        got.append((ctx.download(B.F_ACCEL_RADIAL), ctx.download(B.F_ACCEL_AZIMUTHAL)))
+        ctx.close()
+    for a, b in zip(*got):
+        assert a.shape == (nr + 1, nphi)
+        assert not a[0].any() and not a[nr].any() and np.abs(b[1:nr]).max() > 0
+        assert rel_err(a, b) <= 1e-12
+    # and the grids do not exist without the switch
+    d.body_force_from_potential = 1
+    ctx = driver.make_context(product, d, radii=radii, bodies=tuple(bodies))
+    with pytest.raises(B.FcptError, match="FCPT_EINVAL"):
+        ctx.download(B.F_ACCEL_RADIAL)
+    ctx.close()
+
+
+@pytest.mark.parametrize("law", ["lin", "bell"])
+def test_tabulated_opacity_laws_over_all_regions(product, oracle, law):
+    """Opacity: Lin | Bell (src/opacity.cpp:45-297) in cooling_terms(): Q- of the init call and the state after five
+    steps of a disk whose cells sweep rho = 1e-13 .. 1e-4 g/cm^3, T = 10 .. 1e7 K (every region of both laws)."""
+    from fargocpt_amd import driver
+    from tests.opacity_cases import sweep_state
+    d, radii, fields, _ = sweep_state(product, B.OPACITY_LIN if law == "lin" else B.OPACITY_BELL, nr=40, nphi=192)
+    got = []
+    for lib in (product, oracle):
+        ctx = driver.make_context(lib, d, fields=fields, radii=radii)
+        got.append(ctx.download(B.F_QMINUS))
+        ctx.close()
+    assert (got[1][1:-1] > 0).all()
+    assert np.abs(got[0] / np.where(got[1] != 0, got[1], 1.0) - (got[1] != 0)).max() <= 1e-11
+
+
+def test_half_limiter_edge_cases(product):
+    """The branch-free van Leer half slope of the transport kernels (max(ab, 0) times a guarded reciprocal) against
+    the select form `ab > 0 ? ab / (a + b) : 0` of TransportEuler.cpp:306-312 on the inputs where they could part:
+    +-0, +-denormal sums, sums that cancel, huge and tiny operands of either sign (a negative
+    denormal sum gave NaN).  Ordinary operands: <= 2 ulp (reciprocal + Newton step instead of the division)."""
+    rng = np.random.default_rng(5)
+    tiny = np.array([0.0, -0.0, 5e-324, -5e-324, 1e-310, -1e-310, 2.2250738585072014e-308, -2.2250738585072014e-308,
+                     1e-300, -1e-300, 1e-200, -1e-200, 1.0, -1.0, 1e150, -1e150, 1e300, -1e300])
+    a, b = (x.ravel() for x in np.meshgrid(tiny, tiny))
+    ra = rng.standard_normal(4096) * 10.0 ** rng.uniform(-30, 30, 4096)
+    rb = ra * rng.uniform(-2.0, 3.0, 4096)
+    a, b = np.concatenate([a, ra, ra, 1.0 + rng.uniform(-1e-15, 1e-15, 64)]), np.concatenate([b, rb, -ra, -np.ones(64)])
+    got = product.selftest_half_limiter(B.LIMITER_VANLEER, a, b)
+    with np.errstate(all="ignore"):
+        ab = a * b
+        want = np.where(ab > 0, ab / (a + b), 0.0)
+    fin = np.isfinite(want)                      # (ab overflows for |a|, |b| ~ 1e300 in either form)
+    bad = fin & ~np.isfinite(got)
+    assert not bad.any(), (a[bad], b[bad], got[bad])
+    zero = want == 0.0
+    assert (got[zero] == 0.0).all()
+    ok = fin & (np.abs(want) > 1e-290)           # (results in the denormal range carry fewer bits in either form)
+    assert np.abs(got[ok] / want[ok] - 1.0).max() <= 5e-16

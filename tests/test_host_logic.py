@@ -165,8 +165,8 @@ def test_hot_kernel_occupancy_budget():
         # cell-local CFL terms parks up to seven dwords in scratch
         "17k_transport_fusedILi1ELb1ELb1ELi0E": (4, 0),
         "23k_transport_fused_thermILi1ELb1ELb1ELi0E": (4, 32),
-        "14k_source_marchILi1ELb0E": (6, 0),              # isothermal source step, TW artificial viscosity
-        "14k_source_marchILi1ELb1E": (4, 0),              # ... with StabilizeViscosity
+        "14k_source_marchILi1ELb0ELb0E": (6, 0),            # isothermal source step, TW artificial viscosity
+        "14k_source_marchILi1ELb1ELb0E": (4, 0),            # ... with StabilizeViscosity
         # ideal EOS, potential in the kernel, no cooling terms: one loop-invariant pair lives in scratch since the pair
         # reciprocals are carried through the window (measured: -1.4 % per step with it)
         "18k_source_march_adiILi1ELb1E": (4, 16),

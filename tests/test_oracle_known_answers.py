@@ -304,3 +304,24 @@ def test_stabilize_viscosity_factors_are_the_jacobian_diagonal(product, oracle, 
     # the factor misses tau_rphi(Nr) = 0, which the update never needs
     np.testing.assert_allclose(cphi[1:nr - 1], jp[1:nr - 1], rtol=1e-11)
     np.testing.assert_allclose(cr[1:nr], jr[1:nr], rtol=1e-11)
+
+
+@pytest.mark.parametrize("law", ["lin", "bell"])
+def test_tabulated_opacity_laws_against_an_independent_statement(product, oracle, law):
+    """Opacity: Lin | Bell (src/opacity.cpp:45-168 | 170-297) have no fixture in the reference's tests (its setups
+    use the constant and the T^2 law): "parity unpinned" for these two switches.  What can be checked here is the
+    oracle's C restatement against a second, vectorised statement of the same published fits (tests/opacity_cases.py)
+    on a state whose cells sweep rho = 1e-13 .. 1e-4 g/cm^3 and T = 10 .. 1e7 K -- all eight regions and their
+    borders -- through the quantity the path consumes: Q- of thermal_cooling at init."""
+    from fargocpt_amd import binding as B, driver
+    from tests.opacity_cases import sweep_state, qminus_numpy, lin_numpy, bell_numpy
+    d, radii, fields, rmed = sweep_state(product, B.OPACITY_LIN if law == "lin" else B.OPACITY_BELL)  # (host-side helpers)
+    ctx = driver.make_context(oracle, d, fields=fields, radii=radii)
+    q = ctx.download(B.F_QMINUS)
+    ctx.close()
+    want, kappa = qminus_numpy(d, fields[0], fields[3], rmed, lin_numpy if law == "lin" else bell_numpy)
+    inner = slice(1, d.nr_global - 1)
+    assert np.isfinite(q).all() and (q[inner] > 0).all()
+    assert np.abs(q[inner] / want[inner] - 1.0).max() < 1e-9
+    # the sweep really crosses the regions: opacities from the ice-grain branch to electron scattering
+    assert kappa.min() < 1e-3 and kappa.max() > 1e3 and np.isclose(kappa[-1, -1], 0.348, rtol=0.05)
