@@ -827,6 +827,9 @@ int fcpt_set_clock(fcpt_ctx *c, const fcpt_clock *in)
     k.n_hydro_iter = in->n_hydro_iter;
     k.n_monitor = in->n_monitor;
     k.n_snapshot = in->n_snapshot;
+    // (the shift-jump stamps of k_ring_mean are sequence numbers derived from n_hydro_iter: none may survive a clock
+    //  that is set back)
+    HIPCHK(hipMemsetAsync(c->P.shift_jump, 0, 4 * sizeof(int), c->stream));
     *c->h_clk = k;
     HIPCHK(hipMemcpyAsync(c->P.clk, c->h_clk, sizeof(DevClock), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -182,3 +182,13 @@ __device__ __forceinline__ double wave_sum(double x)
     x = dpp_add<0x143, 0xc>(x); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
     return x;
 }
+
+// The shift-jump stamps of a transport (k_ring_mean, kernels/transport.h): sequence number of the current step ...
+#define SHIFT_SEQ(clk_) ((int)(((clk_)->n_hydro_iter + 1ull) & 0x7fffffffull))
+// true if the transport whose k_ring_mean ran last found a ring pair beyond the one-lane shift of k_transport_fused
+// (written by an earlier kernel, never by the reading one: scalar loads through the constant address space)
+__device__ __forceinline__ bool shift_jump_raised(const int *flag)
+{
+    const int __attribute__((address_space(4))) *f = (const int __attribute__((address_space(4))) *)flag;
+    return f[0] == f[2];
+}

@@ -458,33 +458,6 @@ static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, 
 #undef MARCHC
 #undef MARCHK
 
-// k_transport_fallback: radial sweep, grid barrier, azimuthal march behind one idle check
-static void launch_fallback(const Dev &P, const Dev &Wm, hipStream_t st)
-{
-    const int n_cu = device_cus();
-    ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
-    const Launch2D l = launch2d((P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS, P.nphi);
-    const int gx = (int)l.grid.x, gy = (int)l.grid.y;
-    const int tstride = 64 * 2 - (THETA_LO + THETA_HI);
-    const int tiles = (P.nphi + tstride - 1) / tstride;
-    const int rows = P.opt.theta_rows > 0 ? P.opt.theta_rows : THETA_ROWS;
-    const int nvb_theta = (((P.nr + rows - 1) / rows) * tiles + 3) / 4;
-    int blocks = gx * gy > nvb_theta ? gx * gy : nvb_theta;
-    blocks = blocks > FALLBACK_BLOCKS ? FALLBACK_BLOCKS : blocks;
-    blocks = blocks > n_cu ? n_cu : blocks; // the grid barrier needs every workgroup resident
-    const dim3 grid(blocks), block(256);
-    if (P.adiabatic) {
-        if (Wm.damp_in_step)
-            KLAUNCH(KID_TRANSPORT_FALLBACK, (k_transport_fallback<true, true>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
-        else
-            KLAUNCH(KID_TRANSPORT_FALLBACK, (k_transport_fallback<true, false>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
-    } else {
-        if (Wm.damp_in_step)
-            KLAUNCH(KID_TRANSPORT_FALLBACK, (k_transport_fallback<false, true>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
-        else
-            KLAUNCH(KID_TRANSPORT_FALLBACK, (k_transport_fallback<false, false>), grid, block, P, Wm, inB, gx, gy, tiles, rows, nvb_theta, P.shift_jump);
-    }
-}
 // the fused kernel runs, nothing is queued behind it, and there are chunks between the two ends
 bool transport_can_split(const Dev &P, bool shear_safe)
 {
@@ -527,8 +500,8 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         const int tstride = 64 * CF - (CF == 2 ? TfHalo<2>::lo + TfHalo<2>::hi : TfHalo<1>::lo + TfHalo<1>::hi);
         const int tiles = (P.nphi + tstride - 1) / tstride;
         const int chunks = (P.nr + rows - 1) / rows;
-        // The two-kernel transport is always queued behind the fused kernel (two idle launches, 7 us of a 0.39 ms
-        // step) and runs only if a ring pair exceeds the one-lane shift.  The CFL condition's shear limit
+        // The azimuthal half of the two-kernel transport is always queued behind the fused kernel (one idle launch) and
+        // runs only if a ring pair exceeds the one-lane shift.  The CFL condition's shear limit
         // (cfl.cpp:207-220) bounds |Nshift[i] - Nshift[i-1]| for the velocities it saw, but the source step that
         // follows can change v_phi enough to break it in violent flows (the fuzzer found one: an ideal-gas
         // spreading ring), and the reference shifts by any amount.  FCPT_TRANSPORT_FALLBACK=0 drops the launches
@@ -579,14 +552,12 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
 #undef TFC
 #undef TFK
 #undef TFK2
-        // behind it, the two-kernel form: its blocks return at once unless the fused kernel met
-        // |Nshift[i] - Nshift[i-1]| > 1 (a time step beyond the FARGO shear limit)
-        if (P.opt.transport_fallback == 2) { // the two sweeps as two launches (the form of round 1)
-            launch_radial(P, P.shift_jump, st);
+        // behind it, the azimuthal march of the two-kernel form: its blocks return at once unless k_ring_mean met
+        // |Nshift[i] - Nshift[i-1]| > 1 (a time step beyond the FARGO shear limit) -- the fused launch then ran the
+        // radial sweep.  (Round 2 did both sweeps in this second launch with a hand-rolled grid barrier between them;
+        // the flag now being known before the fused launch starts, no barrier is needed.)
+        if (fallback)
             launch_theta_march(P, Wm, 2, 0, 0, P.shift_jump, st);
-        } else if (fallback) {
-            launch_fallback(P, Wm, st);
-        }
         res.marched = tiles;
         res.thermal = CF == 1 && P.adiabatic && Wm.cfl_thermal != nullptr;
         res.sigma = Wm.sigma, res.energy = Wm.energy, res.vrad = Wm.vrad, res.vazi = Wm.vazi;

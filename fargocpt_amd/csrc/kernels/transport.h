@@ -218,7 +218,7 @@ template <bool ROWU> __device__ __forceinline__ void transport_radial_block(cons
 // few hundred blocks that return at once, not thousands).
 template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(const Dev P, const int *only_if, int gx, int gy)
 {
-    if (only_if && !*only_if)
+    if (only_if && !shift_jump_raised(only_if))
         return;
     for (int vb = blockIdx.x; vb < gx * gy; vb += gridDim.x)
         transport_radial_block<ROWU>(P, vb, gx, gx * gy);
@@ -228,17 +228,20 @@ template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(c
 // one wavefront per ring (4 rings per block), 16-byte loads with 16 in flight per lane, a
 // butterfly for the ring sum; the per-ring scalars of the epilogue are fetched up front so the
 // last lane-0 instructions do not queue behind three dependent memory round trips.
-__global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, const double *part, int nparts, int pstride)
+//
+// with_shift: the launch also decides whether this transport can take the one-kernel form: k_transport_fused covers
+// |Nshift[i] - Nshift[i-1]| <= 1 (cyclic) for all ring pairs.  Every wavefront compares its ring's shift with the
+// previous ring's (its block neighbour's through LDS; the first wavefront of a block sums ring i-1 once more itself)
+// and a pair beyond the limit stamps shift_jump[0] with this transport's sequence number, which the wavefront of ring
+// 0 leaves in shift_jump[2]: the kernels behind this one test shift_jump[0] == shift_jump[2].  Nothing is ever reset
+// (a reset by one wavefront would race with the stamps of the others), and because the flag is known before
+// k_transport_fused starts, that launch itself runs the radial sweep of the two-kernel form when it is raised --
+// one gated azimuthal launch behind it completes the step, with no grid-wide barrier anywhere.
+__device__ __forceinline__ double ring_sum_vphi(const Dev &P, int i, int lane, const double *part, int nparts, int pstride)
 {
     // part != nullptr: the producer kernel left nparts partial sums per ring (fixed order, so the
     // result is deterministic); rings rewritten afterwards by a boundary condition are re-summed
     // from the grid.
-    const int lane = threadIdx.x & 63;
-    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (i >= P.nr)
-        return;
-    const double dt = with_shift ? P.clk->dt : 1.0;
-    const double invr = P.InvRmed[i], rmed = P.Rmed[i];
     const bool ghost = (i == 0 && P.is_first && P.bc_vaz[0] != FCPT_BC_NONE) ||
                        (i == P.nr - 1 && P.is_last && P.bc_vaz[1] != FCPT_BC_NONE) ||
                        (!P.is_first && i < FCPT_OVERLAP) || (!P.is_last && i >= P.nr - FCPT_OVERLAP);
@@ -273,33 +276,74 @@ __global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, 
     }
     for (int off = 32; off > 0; off >>= 1)
         acc += __shfl_down(acc, off, 64);
-    if (lane == 0) {
-        const double mean = acc / (double)P.nphi;
-        P.vmean[i] = mean;
-        if (with_shift && i == 0) {
-            P.shift_jump[0] = 0; // raised by k_transport_fused if a ring pair is beyond its one-lane shift
-            P.shift_jump[1] = 0; // arrival counter of k_transport_fallback's grid barrier
+    return acc; // lane 0 holds the sum
+}
+// Nshift of a ring from its mean (ComputeConstantResidual, :207-236)
+__device__ __forceinline__ double ring_ntilde(const Dev &P, int i, double mean, double dt) { return mean * P.InvRmed[i] * dt * P.invdphi; }
+
+__global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, const double *part, int nparts, int pstride)
+{
+    __shared__ int s_nshift[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + w);
+    const bool active = i < P.nr;
+    const double dt = with_shift ? P.clk->dt : 1.0;
+    int my_shift = 0;
+    if (active) {
+        const double invr = P.InvRmed[i], rmed = P.Rmed[i];
+        const double acc = ring_sum_vphi(P, i, lane, part, nparts, pstride);
+        if (with_shift) { // (all lanes: the shift is needed wave-uniform below)
+            const double mean0 = __shfl(acc, 0, 64) / (double)P.nphi;
+            my_shift = (int)floor(ring_ntilde(P, i, mean0, dt) + 0.5);
         }
-        if (with_shift) {
-            const double invdt = 1.0 / dt;
-            const double Ntilde = mean * invr * dt * P.invdphi;
-            const double Nround = floor(Ntilde + 0.5);
-            P.nshift[i] = (int)Nround;
-            const double vc = (Ntilde - Nround) * rmed * invdt * P.dphi;
-            P.vconst[i] = vc;
-            ShiftRow sr;
-            sr.mean = mean, sr.vconst = vc, sr.nshift = (int)Nround, sr.pad0 = 0, sr.pad1[0] = sr.pad1[1] = 0.0;
-            const DampRow dr = P.damp_tab[i]; // damping.cpp:311-427: X <- (X - X0) exp(-dt f / tau) + X0
-            sr.es = exp(-dt * dr.fs / dr.ts);
-            sr.ev = exp(-dt * dr.fv / dr.tv);
-            sr.ev_top = 1.0;
-            if (i == P.nr - 1) {
-                const DampRow dn = P.damp_tab[P.nr];
-                sr.ev_top = exp(-dt * dn.fv / dn.tv);
+        if (lane == 0) {
+            const double mean = acc / (double)P.nphi;
+            P.vmean[i] = mean;
+            if (with_shift && i == 0)
+                P.shift_jump[2] = SHIFT_SEQ(P.clk); // this transport's sequence number
+            if (with_shift) {
+                const double invdt = 1.0 / dt;
+                const double Ntilde = mean * invr * dt * P.invdphi;
+                const double Nround = floor(Ntilde + 0.5);
+                P.nshift[i] = (int)Nround;
+                const double vc = (Ntilde - Nround) * rmed * invdt * P.dphi;
+                P.vconst[i] = vc;
+                ShiftRow sr;
+                sr.mean = mean, sr.vconst = vc, sr.nshift = (int)Nround, sr.pad0 = 0, sr.pad1[0] = sr.pad1[1] = 0.0;
+                const DampRow dr = P.damp_tab[i]; // damping.cpp:311-427: X <- (X - X0) exp(-dt f / tau) + X0
+                sr.es = exp(-dt * dr.fs / dr.ts);
+                sr.ev = exp(-dt * dr.fv / dr.tv);
+                sr.ev_top = 1.0;
+                if (i == P.nr - 1) {
+                    const DampRow dn = P.damp_tab[P.nr];
+                    sr.ev_top = exp(-dt * dn.fv / dn.tv);
+                }
+                P.shift_tab[i] = sr;
             }
-            P.shift_tab[i] = sr;
         }
     }
+    if (!with_shift)
+        return;
+    // ---- ring pairs beyond the one-lane shift -----------------------------------------------------------------------
+    if (lane == 0)
+        s_nshift[w] = my_shift;
+    __syncthreads();
+    if (!active || i == 0)
+        return;
+    int prev_shift;
+    if (w > 0) {
+        prev_shift = s_nshift[w - 1];
+    } else { // the ring below belongs to another workgroup: its sum once more
+        const double acc = ring_sum_vphi(P, i - 1, lane, part, nparts, pstride);
+        const double mean_p = __shfl(acc, 0, 64) / (double)P.nphi;
+        prev_shift = (int)floor(ring_ntilde(P, i - 1, mean_p, dt) + 0.5);
+    }
+    const int nphi = P.nphi;
+    int dd = my_shift % nphi - prev_shift % nphi;
+    dd = dd < 0 ? -dd : dd;
+    dd = dd > nphi / 2 ? nphi - dd : dd;
+    if (dd > 1 && lane == 0)
+        P.shift_jump[0] = SHIFT_SEQ(P.clk);
 }
 
 // Upwind star state at azimuthal interface k (between cells k-1 and k),
@@ -811,48 +855,8 @@ template <int C, bool ADI, bool DAMP, bool PER>
 __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const double *va_pre, const double *vr_pre, ThetaSet in,
                                                               int tiles, int rows, int advance_clock, const int *only_if, int nvb)
 {
-    if (only_if && !*only_if)
+    if (only_if && !shift_jump_raised(only_if))
         return;
     for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x)
         transport_theta_march_block<C, ADI, DAMP, PER>(P, va_pre, vr_pre, in, tiles, rows, advance_clock, vb, nvb);
-}
-
-// The device-side fallback of k_transport_fused in ONE launch.  Its workgroups return at once unless that kernel raised
-// flag[0] (a ring pair beyond the one-lane shift: a dt beyond the FARGO shear limit, or a source step that changed
-// v_phi violently); then they do what k_transport_radial and k_transport_theta_march do, with a grid-wide barrier
-// between the two sweeps (the azimuthal march reads the momenta set B of neighbouring columns and rings).  The barrier
-// is safe because the grid is capped at the number of compute units (every workgroup is resident: 256 threads,
-// <= 128 VGPRs) and its spin is bounded: a workgroup that gives up reports the step as invalid (shear_error) instead
-// of hanging.  Only the rare path pays for the device-scope fences.
-template <bool ADI, bool DAMP>
-__global__ void __launch_bounds__(256) k_transport_fallback(const Dev P, const Dev W, ThetaSet in, int gx, int gy, int tiles,
-                                                           int rows, int nvb_theta, int *flag)
-{
-    if (!flag[0])
-        return;
-    for (int vb = blockIdx.x; vb < gx * gy; vb += gridDim.x)
-        transport_radial_block<true>(P, vb, gx, gx * gy);
-    __syncthreads();
-    __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        __threadfence(); // this workgroup's part of set B is visible device-wide before it reports in
-        atomicAdd(&flag[1], 1);
-        int ok = 0;
-        for (int spin = 0; spin < (1 << 22); ++spin) {
-            if (__hip_atomic_load(&flag[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x) {
-                ok = 1;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(32);
-        }
-        __threadfence();
-        if (!ok)
-            W.clk->shear_error = 2; // the other workgroups never arrived: the step is not computed
-        s_ok = ok;
-    }
-    __syncthreads();
-    if (!s_ok)
-        return;
-    for (int vb = blockIdx.x; vb < nvb_theta; vb += gridDim.x)
-        transport_theta_march_block<2, ADI, DAMP, false>(W, P.vazi, P.vrad, in, tiles, rows, 0, vb, nvb_theta);
 }

@@ -17,7 +17,8 @@
 // v_r(i) couples rings i-1 and i at one post-shift column, i.e. at lanes that differ by
 // Nshift[i] - Nshift[i-1].  The FARGO shear limit of the CFL condition (cfl.cpp:207-220) keeps
 // that difference in {-1, 0, 1} for every admissible dt, so one lane shift of the previous ring
-// is enough; k_ring_mean raises P.shift_jump otherwise and the unfused kernels run instead.
+// is enough; k_ring_mean raises P.shift_jump otherwise and this launch does the radial sweep of the
+// two-kernel transport instead (see there).
 // Nothing intermediate reaches memory: 3 (4) grids read + 3 (4) written instead of 8 + 9
 // (10 + 11) doubles per cell for k_transport_radial + k_transport_theta_march.
 // Validity in cells of a 64*C segment: right 1 (L+ needs v_phi(j+1)), 4 at either end for the
@@ -76,6 +77,22 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     // chunks in radial order on contiguous XCD ranges the outer zone's wavefronts started last, on one XCD, and ran
     // on alone (2.98 of 4 wavefronts per SIMD on average; -5.5 % kernel time, -3 % / -4.6 % per step, three A/B pairs).
     // (launches of fewer than TF_XCD_CHUNKS chunks -- short slabs -- deal workgroups instead: every XCD gets work)
+    if (ch.advance_clock && blockIdx.x == 0 && threadIdx.x == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
+        clock_advance(W.clk, P.clk->dt);
+    }
+    // k_ring_mean found a ring pair beyond the one-lane shift (a dt beyond the FARGO shear limit, or a source step that
+    // changed v_phi violently): this launch runs the radial sweep of the two-kernel transport instead -- all of its
+    // workgroups, with a grid stride -- and the gated azimuthal launch queued behind it finishes the step.
+    if (shift_jump_raised(P.shift_jump)) {
+        if (has_fallback) {
+            const int gx = (P.nphi + 255) / 256, gy = (P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS; // launch2d() of Nphi >= 256
+            for (int vb = blockIdx.x; vb < gx * gy; vb += gridDim.x)
+                transport_radial_block<true>(P, vb, gx, gx * gy);
+        } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+            W.clk->shear_error = 1; // nothing behind this kernel will redo the step: report it
+        }
+        return;
+    }
     int chunk_l, wave;
     if (ch.count >= TF_XCD_CHUNKS) {
         const int xcd = blockIdx.x & 7, wq = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -96,31 +113,6 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     if (r0 >= nr)
         return;
     const int r1 = r0 + rows < nr ? r0 + rows : nr;
-    if (ch.advance_clock && wave == 0 && lane == 0) { // sim::time += dt; N_hydro_iter++ (simulation.cpp:226-227)
-        clock_advance(W.clk, P.clk->dt);
-    }
-    { // the lane shift of the previous ring covers |Nshift[i] - Nshift[i-1]| <= 1 only: one ring per lane (the ring by
-      // ring form was a chain of rows dependent scalar loads, 2 us at the start of every wavefront)
-        bool jump = false;
-        for (int base = r0; base < r1; base += 63) { // lane 0 holds the ring below the 63 this pass tests
-            const int i = base - 1 + lane;
-            const int ic = i < 0 ? 0 : (i > r1 - 1 ? r1 - 1 : i);
-            const int cur = P.nshift_c[ic] % nphi;
-            const int prev = __builtin_amdgcn_update_dpp(cur, cur, 0x138, 0xf, 0xf, false); // wave_shr:1
-            int dd = cur - prev;
-            dd = dd < 0 ? -dd : dd;
-            dd = dd > nphi / 2 ? nphi - dd : dd;
-            jump = jump || __builtin_amdgcn_ballot_w64(lane >= 1 && i < r1 && dd > 1) != 0;
-        }
-        if (jump) {
-            if (lane == 0) {
-                *P.shift_jump = 1;
-                if (!has_fallback) // nothing behind this kernel will redo the step: report it
-                    W.clk->shear_error = 1;
-            }
-            return;
-        }
-    }
     const int tile = wave - chunk_l * tiles;
     const int stride = 64 * C - (LO + HI);
     const int a = tile * stride - LO; // first pre-shift column of the segment

@@ -786,4 +786,4 @@ def test_half_limiter_edge_cases(product):
     zero = want == 0.0
     assert (got[zero] == 0.0).all()
     ok = fin & (np.abs(want) > 1e-290)           # (results in the denormal range carry fewer bits in either form)
-    assert np.abs(got[ok] / want[ok] - 1.0).max() <= 5e-16
+    assert np.abs(got[ok] / want[ok] - 1.0).max() <= 4e-15   # v_rcp_f64 + one Newton step + the product: a few ulp

@@ -163,7 +163,10 @@ def test_hot_kernel_occupancy_budget():
         "17k_transport_fusedILi1ELb0ELb1ELi0E": (4, 0),   # isothermal, damping folded in, van Leer: the bench kernel
         # ideal EOS: 4 waves since round 2 (register diet + waves_per_eu); the instantiation that also stores the
         # cell-local CFL terms parks up to seven dwords in scratch
-        "17k_transport_fusedILi1ELb1ELb1ELi0E": (4, 0),
+        # (round 3: one value of the rare in-launch radial sweep -- taken when k_ring_mean raised the shift-jump flag --
+        #  is parked in scratch across its grid-stride loop: one store and one reload per wavefront OF THAT PATH, none
+        #  in the marching loop)
+        "17k_transport_fusedILi1ELb1ELb1ELi0E": (4, 16),
         "23k_transport_fused_thermILi1ELb1ELb1ELi0E": (4, 32),
         "14k_source_marchILi1ELb0ELb0E": (6, 0),            # isothermal source step, TW artificial viscosity
         "14k_source_marchILi1ELb1ELb0E": (4, 0),            # ... with StabilizeViscosity
