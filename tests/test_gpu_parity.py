@@ -253,6 +253,40 @@ def test_transport_beyond_shear_limit_falls_back(product, oracle, monkeypatch):
         run_pair(product, oracle, d, 3, bodies=bodies, dt_scale=4.0)
 
 
+def test_fallback_in_three_slabs_and_back_to_the_fused_kernel(product, oracle):
+    """Round 3: the shift-jump flag is a sequence stamp left by k_ring_mean (nothing resets it), the fused launch runs
+    the radial sweep itself when it is raised and one gated azimuthal launch finishes the step -- no grid barrier.
+    (a) three slabs of one process, energy equation, steps of 4x the CFL step: each slab decides for itself (the
+    shear is strongest in the inner slab), all paths must give the oracle's single-slab result; (b) a context that
+    has just taken the fallback path takes the fused kernel again in the next, ordinary step (a stale stamp would
+    keep it on the two-kernel path for ever): k_transport_theta_march's gated launch returns at once, which shows in
+    its run time."""
+    from fargocpt_amd import driver
+    d = setups.planet_disk(product, 96, 512, adiabatic=True)
+    d.damping = 0
+    d.first_dt = 1.0
+    _check(run_pair(product, oracle, d, 3, bodies=setups.jupiter_bodies(d), dt_scale=4.0, nslabs=(3, 1)),
+           ("sigma", "vrad", "vazi", "energy"))
+    d = setups.planet_disk(product, 48, 512)   # (coarse in radius: the shear between neighbouring rings is what limits dt)
+    d.damping = 0
+    d.first_dt = 1.0
+    names = product.kernel_names()
+    ctx = driver.make_context(product, d, bodies=setups.jupiter_bodies(d))
+    S = driver.SlabSet([ctx])
+    S.prepare()
+    times = {}
+    for label, scale in (("ordinary", 1.0), ("beyond", 4.0), ("ordinary again", 1.0)):
+        S.dt_scale = scale
+        ctx.profile_start([names.index("k_transport_theta_march"), names.index("k_transport_fused")], max_launches=16)
+        S.run(2)
+        prof = ctx.profile_stop()
+        times[label] = prof["k_transport_theta_march"][0] / prof["k_transport_theta_march"][1]
+        assert prof["k_transport_theta_march"][1] == 2 and prof["k_transport_fused"][1] == 2
+    ctx.close()
+    assert times["beyond"] > 5 * times["ordinary"], times          # the gated launch did the azimuthal march
+    assert times["ordinary again"] < 2 * times["ordinary"], times  # ... and is idle again afterwards
+
+
 @pytest.mark.parametrize("adiabatic", [False, True])
 def test_disk_on_body_accel(product, oracle, adiabatic):
     """ComputeDiskOnPlanetAccel (Force.cpp:23-122): the four sums (inner /
