@@ -709,6 +709,15 @@ int fcpt_get_option(const fcpt_ctx *c, const char *name, int32_t *value)
         *value = (int32_t)(c->graph_replays > 0x7fffffffll ? 0x7fffffffll : c->graph_replays);
         return FCPT_OK;
     }
+    if (!std::strcmp(name, "transport_fell_back")) { // 1: the last transport met a ring pair beyond the one-lane shift
+        fcpt_ctx *m = const_cast<fcpt_ctx *>(c);      //    and took the two-kernel path (blocks: reads the device stamps)
+        int stamps[4] = {0, 0, 0, 0};
+        join_side(m);
+        HIPCHK(hipMemcpyAsync(stamps, c->P.shift_jump, sizeof(stamps), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *value = (stamps[2] != 0 && stamps[0] == stamps[2]) ? 1 : 0;
+        return FCPT_OK;
+    }
     if (!std::strcmp(name, "coop_active")) { // 1: fcpt_run_steps takes the one-kernel-per-step path on this grid
         *value = c->coop_active ? 1 : 0;
         return FCPT_OK;

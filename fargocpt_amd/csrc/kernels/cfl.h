@@ -7,18 +7,18 @@
 // min_cells dt_cell == CFL / sqrt(max_cells sum): k_cfl_cells reduces the per-cell sums to one
 // maximum per block (no atomics); k_cfl_final folds the block maxima, applies sqrt and the
 // quotient once, and adds the per-ring FARGO shear limit (:207-220).
-#define CFL_ROWS 8
+#define CFL_ROWS 8 /* on grids that fill the GPU; fewer on small ones (march_len, launch.h) */
 // One thread owns a phi column and walks CFL_ROWS rings (v_r(i+1) of one ring is v_r(i) of the
 // next, so every value is loaded once); per-block maxima, no atomics.
-template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part)
+template <bool ROWU> __global__ void k_cfl_cells(const Dev P, double *part, int rows)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r0_ = P.first_active + (blockIdx.y * blockDim.y + threadIdx.y) * CFL_ROWS;
+    const int r0_ = P.first_active + (blockIdx.y * blockDim.y + threadIdx.y) * rows;
     const int r0 = ROWU ? __builtin_amdgcn_readfirstlane(r0_) : r0_;
     double s = 0.0;
     if (j < P.nphi && r0 < P.active_size) {
         const int jn = JNEXT;
-        const int r1 = r0 + CFL_ROWS < P.active_size ? r0 + CFL_ROWS : P.active_size;
+        const int r1 = r0 + rows < P.active_size ? r0 + rows : P.active_size;
         const double lf = P.leapfrog ? 0.6 : 1.0;
         const double C2 = P.art_visc_factor * P.art_visc_factor;
         const double gg1 = P.gamma * (P.gamma - 1.0), inv_sqrt_gamma = 1.0 / sqrt(P.gamma);

@@ -148,6 +148,21 @@ static int device_cus()
     }
     return n_cu;
 }
+// Rings per thread (or wavefront) of the marching kernels of the per-loop path (k_transport_radial, k_cfl_cells,
+// k_transport_theta_march): a thread that owns `rows` rings is a serial chain of rows (+ pre-roll) dependent
+// iterations, which pays off only when there are more cells than the GPU has lanes to put them on.  On the small
+// grids of the reference's tests the shortest chain wins (measured, round 3, shock tube 4096 x 4: k_transport_radial
+// 31.5 us at 16 rings per thread, k_transport_theta_march 27.6 us at 8 rings per wavefront -- 57 % of a 104 us step of
+// 15 launches; profiles/r03_narrow_kernels.txt).
+static int march_len(const Dev &P, int rows_full)
+{
+    const long lanes = (long)device_cus() * 4 * 8 * 64; // every SIMD eight wavefronts deep
+    const long cells = (long)P.nr * P.nphi;
+    int rows = rows_full;
+    while (rows > 1 && cells / rows < lanes)
+        rows >>= 1;
+    return rows;
+}
 static int source_rows(const Dev &P)
 {
     if (P.opt.source_rows > 0)
@@ -399,13 +414,14 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
 // one radial sweep + ring means (T1-T4); only_if: see k_transport_radial
 static void launch_radial(const Dev &P, const int *only_if, hipStream_t st)
 {
-    const Launch2D l = launch2d((P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS, P.nphi);
+    const int rows = march_len(P, RADIAL_ROWS);
+    const Launch2D l = launch2d((P.nr + rows - 1) / rows, P.nphi);
     const int gx = (int)l.grid.x, gy = (int)l.grid.y;
     const dim3 grid(only_if && gx * gy > FALLBACK_BLOCKS ? FALLBACK_BLOCKS : gx * gy);
     if (l.block.x >= 64)
-        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<true>, grid, l.block, P, only_if, gx, gy);
+        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<true>, grid, l.block, P, only_if, gx, gy, rows);
     else
-        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, grid, l.block, P, only_if, gx, gy);
+        KLAUNCH(KID_TRANSPORT_RADIAL, k_transport_radial<false>, grid, l.block, P, only_if, gx, gy, rows);
 }
 void launch_massflow(const Dev &P, hipStream_t st)
 {
@@ -439,7 +455,7 @@ static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, 
     ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     const int tstride = 64 * C - (THETA_LO + THETA_HI);
     const int tiles = periodic ? 1 : (P.nphi + tstride - 1) / tstride;
-    const int rows = P.opt.theta_rows > 0 ? P.opt.theta_rows : THETA_ROWS;
+    const int rows = P.opt.theta_rows > 0 ? P.opt.theta_rows : march_len(P, THETA_ROWS);
     const int chunks = (P.nr + rows - 1) / rows;
     const int waves = chunks * tiles;
     const int nvb = (waves + 3) / 4;
@@ -675,12 +691,13 @@ void launch_cfl(const Dev &P, int apply_policy, hipStream_t st, bool interior_do
     const int nrows = P.active_size - P.first_active;
     int nparts = 0;
     if (nrows > 0) {
-        const Launch2D l = launch2d((nrows + CFL_ROWS - 1) / CFL_ROWS, P.nphi);
+        const int rows = march_len(P, CFL_ROWS);
+        const Launch2D l = launch2d((nrows + rows - 1) / rows, P.nphi);
         nparts = (int)(l.grid.x * l.grid.y);
         if (l.block.x >= 64)
-            KLAUNCH(KID_CFL_CELLS, k_cfl_cells<true>, l.grid, l.block, P, P.cfl_part);
+            KLAUNCH(KID_CFL_CELLS, k_cfl_cells<true>, l.grid, l.block, P, P.cfl_part, rows);
         else
-            KLAUNCH(KID_CFL_CELLS, k_cfl_cells<false>, l.grid, l.block, P, P.cfl_part);
+            KLAUNCH(KID_CFL_CELLS, k_cfl_cells<false>, l.grid, l.block, P, P.cfl_part, rows);
     }
     KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, nparts, apply_policy);
 }

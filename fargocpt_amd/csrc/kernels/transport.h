@@ -119,7 +119,7 @@ template <bool ROWU> __global__ void k_massflow(const Dev P)
 // is evaluated once and each ring is loaded once per chunk (+4 halo rings).
 // The specific momenta Work = (Sigma v)/Sigma are formed as v directly (equal to
 // the reference's quotient to within 1 ulp).
-#define RADIAL_ROWS 16
+#define RADIAL_ROWS 16 /* rings per thread on grids that fill the GPU; fewer on small ones (march_len, launch.h) */
 
 struct RadialRow { // specific quantities of one ring at this column (er: the energy itself)
     double s, rmp, rmm, lp, lm, e, er;
@@ -166,18 +166,18 @@ __device__ __forceinline__ RadialFlux radial_flux(const Dev &P, int k, double v,
     f.e = P.adiabatic ? g * star_radial(P, geo, v, dt, a.e, b.e, c.e, d.e) * rho * v : 0.0;
     return f;
 }
-template <bool ROWU> __device__ __forceinline__ void transport_radial_block(const Dev &P, int vb, int gx, int nvb)
+template <bool ROWU> __device__ __forceinline__ void transport_radial_block(const Dev &P, int vb, int gx, int nvb, int rows)
 {
     const int lb = xcd_block(vb, nvb);
     const int j = (lb % gx) * blockDim.x + threadIdx.x;
-    const int r0_ = ((lb / gx) * blockDim.y + threadIdx.y) * RADIAL_ROWS;
+    const int r0_ = ((lb / gx) * blockDim.y + threadIdx.y) * rows;
     if (j >= P.nphi || r0_ >= P.nr)
         return;
     const int r0 = ROWU ? __builtin_amdgcn_readfirstlane(r0_) : r0_;
     const double dt = P.clk->dt;
     const int jn = JNEXT;
     const int nr = P.nr;
-    const int r1 = r0 + RADIAL_ROWS < nr ? r0 + RADIAL_ROWS : nr;
+    const int r1 = r0 + rows < nr ? r0 + rows : nr;
     auto vr_at = [&](int k) { return (k >= 0 && k <= nr) ? P.vrad[IDX(k, j)] : 0.0; };
     // rings r0-2 .. r0+2 (the last one is the software-prefetched ring of the next iteration:
     // the marching loop is latency-bound unless each ring's loads are issued one iteration
@@ -216,12 +216,12 @@ template <bool ROWU> __device__ __forceinline__ void transport_radial_block(cons
 // virtual block in normal use, and with a small grid as the in-stream fallback of
 // k_transport_fused (only_if: runs only when that kernel gave up; an idle fallback then costs a
 // few hundred blocks that return at once, not thousands).
-template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(const Dev P, const int *only_if, int gx, int gy)
+template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial(const Dev P, const int *only_if, int gx, int gy, int rows)
 {
     if (only_if && !shift_jump_raised(only_if))
         return;
     for (int vb = blockIdx.x; vb < gx * gy; vb += gridDim.x)
-        transport_radial_block<ROWU>(P, vb, gx, gx * gy);
+        transport_radial_block<ROWU>(P, vb, gx, gx * gy, rows);
 }
 
 // compute_average_azimuthal_velocity (:174-189) + ComputeConstantResidual (:207-236):

@@ -87,7 +87,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
         if (has_fallback) {
             const int gx = (P.nphi + 255) / 256, gy = (P.nr + RADIAL_ROWS - 1) / RADIAL_ROWS; // launch2d() of Nphi >= 256
             for (int vb = blockIdx.x; vb < gx * gy; vb += gridDim.x)
-                transport_radial_block<true>(P, vb, gx, gx * gy);
+                transport_radial_block<true>(P, vb, gx, gx * gy, RADIAL_ROWS);
         } else if (blockIdx.x == 0 && threadIdx.x == 0) {
             W.clk->shear_error = 1; // nothing behind this kernel will redo the step: report it
         }

@@ -315,7 +315,9 @@ int fcpt_synchronize(fcpt_ctx *ctx);
  * theta_march, theta_fused, cfl_rings, cfl_split, source_ring_parts, fused_damping, inline_potential, cfl_thermal, bc_fold, comm_overlap,
  * comm_loopback, graph_steps, profile_stride (fcpt_profile_start times every n-th launch of the selected kernels).
  * fcpt_get_option also answers three read-only counters of fcpt_run_steps: graph_replays (hipGraphLaunch calls issued
- * so far), graph_cycle (steps per replay, 0 = no graph), coop_active (1: its steps run as one cooperative kernel each).
+ * so far), graph_cycle (steps per replay, 0 = no graph), coop_active (always 0: a one-kernel step was measured slower than
+ * the launches it would replace), and transport_fell_back (1: the last Transport() met a ring pair
+ * beyond the fused kernel's one-lane shift and took the two-kernel path; blocks).
  * FCPT_EINVAL for an unknown name.  (The reference has no counterpart: its variants are compile-time.) */
 int fcpt_set_option(fcpt_ctx *ctx, const char *name, int32_t value);
 int fcpt_get_option(const fcpt_ctx *ctx, const char *name, int32_t *value);

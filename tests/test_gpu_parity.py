@@ -259,8 +259,7 @@ def test_fallback_in_three_slabs_and_back_to_the_fused_kernel(product, oracle):
     (a) three slabs of one process, energy equation, steps of 4x the CFL step: each slab decides for itself (the
     shear is strongest in the inner slab), all paths must give the oracle's single-slab result; (b) a context that
     has just taken the fallback path takes the fused kernel again in the next, ordinary step (a stale stamp would
-    keep it on the two-kernel path for ever): k_transport_theta_march's gated launch returns at once, which shows in
-    its run time."""
+    keep it on the two-kernel path for ever): the read-only option transport_fell_back reports the stamps."""
     from fargocpt_amd import driver
     d = setups.planet_disk(product, 96, 512, adiabatic=True)
     d.damping = 0
@@ -270,21 +269,16 @@ def test_fallback_in_three_slabs_and_back_to_the_fused_kernel(product, oracle):
     d = setups.planet_disk(product, 48, 512)   # (coarse in radius: the shear between neighbouring rings is what limits dt)
     d.damping = 0
     d.first_dt = 1.0
-    names = product.kernel_names()
     ctx = driver.make_context(product, d, bodies=setups.jupiter_bodies(d))
     S = driver.SlabSet([ctx])
     S.prepare()
-    times = {}
-    for label, scale in (("ordinary", 1.0), ("beyond", 4.0), ("ordinary again", 1.0)):
+    seen = []
+    for scale in (1.0, 4.0, 4.0, 1.0, 1.0):
         S.dt_scale = scale
-        ctx.profile_start([names.index("k_transport_theta_march"), names.index("k_transport_fused")], max_launches=16)
-        S.run(2)
-        prof = ctx.profile_stop()
-        times[label] = prof["k_transport_theta_march"][0] / prof["k_transport_theta_march"][1]
-        assert prof["k_transport_theta_march"][1] == 2 and prof["k_transport_fused"][1] == 2
+        S.run(1)
+        seen.append(ctx.get_option("transport_fell_back"))
     ctx.close()
-    assert times["beyond"] > 5 * times["ordinary"], times          # the gated launch did the azimuthal march
-    assert times["ordinary again"] < 2 * times["ordinary"], times  # ... and is idle again afterwards
+    assert seen == [0, 1, 1, 0, 0], seen
 
 
 @pytest.mark.parametrize("adiabatic", [False, True])
