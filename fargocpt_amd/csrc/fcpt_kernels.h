@@ -21,7 +21,7 @@ enum KernelId {
     KID_TRANSPORT_FUSED, KID_MASSFLOW, KID_CFL_RINGS, KID_TRANSPORT_FALLBACK, KID_EXCHANGE_COPY,
     KID_DISK_ON_BODY, KID_VISC_FACTORS, KID_SOURCE_MARCH_ADI, KID_SOURCE_MARCH_ADI_WIDE,
     KID_TRANSPORT_FUSED_THERM, KID_TRANSPORT_FUSED_WIDE, KID_STEP_COOP, KID_ACCEL_ON_GAS,
-    KID_SOURCE_MARCH_ADI_ACC, KID_COUNT
+    KID_SOURCE_MARCH_ADI_ACC, KID_TRANSPORT_RADIAL_MEANS, KID_COUNT
 };
 static_assert(KID_COUNT <= 64, "fcpt_profile_start selects kernels with a 64-bit mask");
 extern const char *const kKernelNames[KID_COUNT];
@@ -77,7 +77,6 @@ void launch_disk_on_body(const Dev &P, double x, double y, double r_object, doub
 void launch_source_fused(const Dev &P, hipStream_t st);
 int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc = false, bool *bc_folded = nullptr);
 void launch_viscous_fused(const Dev &P, hipStream_t st);
-void launch_substep3_after_fused(const Dev &P, hipStream_t st);
 void launch_derived(const Dev &P, hipStream_t st);
 void launch_pressure(const Dev &P, hipStream_t st);
 void launch_temperature(const Dev &P, hipStream_t st);

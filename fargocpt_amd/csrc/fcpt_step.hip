@@ -60,9 +60,7 @@ bool enqueue_kick(fcpt_ctx *c, bool fold_bc = false)
             ensure_pressure(c);
             launch_source_fused(P, st);          // (v) -> (v_b) -> (v)
             launch_recalculate_viscosity(P, st);
-            launch_viscous_fused(P, st);         // (v) -> (v_b)
-            if (P.adiabatic)
-                launch_substep3_after_fused(P, st);
+            launch_viscous_fused(P, st);         // (v) -> (v_b); ideal EOS: + viscous heating + SubStep3
         }
         return true;
     }

@@ -12,7 +12,8 @@ const char *const kKernelNames[KID_COUNT] = {
     "k_cfl_cells", "k_clock", "k_src_fused", "k_av_fused", "k_visc_fused", "k_source_march",
     "k_transport_theta_march", "k_transport_fused", "k_massflow", "k_cfl_rings", "k_transport_fallback",
     "k_exchange_copy", "k_disk_on_body", "k_visc_factors", "k_source_march_adi", "k_source_march_adi_wide",
-    "k_transport_fused_therm", "k_transport_fused_wide", "k_step_coop", "k_accel_on_gas", "k_source_march_adi_acc"};
+    "k_transport_fused_therm", "k_transport_fused_wide", "k_step_coop", "k_accel_on_gas", "k_source_march_adi_acc",
+    "k_transport_radial_means"};
 
 thread_local Profiler *g_prof = nullptr;
 
@@ -327,14 +328,10 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
 #undef ISOKA
     return ring_sums ? segs : -segs; // < 0: marched, but no ring sums
 }
+// stress tensor + viscous update, and for the energy equation viscous heating and -- cell-local, on the Q+ just
+// formed -- SubStep3 (SourceEuler.cpp:956-1051) with the temperature floor / ceiling behind it (the TEMPERATURE grid
+// the reference refreshes there is read by nothing before recalculate_derived_disk_quantities rewrites it)
 void launch_viscous_fused(const Dev &P, hipStream_t st) { LAUNCH2D(KID_VISC_FUSED, k_visc_fused, P.nr + 1, P); }
-void launch_substep3_after_fused(const Dev &P, hipStream_t st)
-{
-    // SubStep3 (SourceEuler.cpp:956-1051) with Q+ already evaluated by k_visc_fused, and the temperature floor /
-    // ceiling behind it, in one launch (the TEMPERATURE grid the reference refreshes here is read by nothing before
-    // recalculate_derived_disk_quantities rewrites it)
-    LAUNCH2D(KID_SUBSTEP3, k_substep3, P.nr, P, 2);
-}
 
 // viscosity.cpp:256-348: the correction factors depend on nu and Sigma only
 void launch_visc_factors(const Dev &P, hipStream_t st)
@@ -579,8 +576,17 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         res.sigma = Wm.sigma, res.energy = Wm.energy, res.vrad = Wm.vrad, res.vazi = Wm.vazi;
         return res;
     }
-    launch_radial(P, nullptr, st);
-    launch_shift_means(P, st);
+    { // radial sweep + ring means (two independent kernels of the reference's sequence) as one launch
+        const int rows = march_len(P, RADIAL_ROWS);
+        const Launch2D l = launch2d((P.nr + rows - 1) / rows, P.nphi);
+        const int gx = (int)l.grid.x, gy = (int)l.grid.y;
+        const dim3 grid(gx * gy + (P.nr + 3) / 4);
+        const double *part = P.src_ring_nparts ? (const double *)P.ring_part : (const double *)nullptr;
+        if (l.block.x >= 64)
+            KLAUNCH(KID_TRANSPORT_RADIAL_MEANS, k_transport_radial_means<true>, grid, l.block, P, gx, gy, rows, part, P.src_ring_nparts, P.ring_pstride);
+        else
+            KLAUNCH(KID_TRANSPORT_RADIAL_MEANS, k_transport_radial_means<false>, grid, l.block, P, gx, gy, rows, part, P.src_ring_nparts, P.ring_pstride);
+    }
     ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
     ThetaOut outA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};
     ThetaSet inA = {P.rmpA, P.rmmA, P.lpA, P.lmA, P.sigA, P.eA};

@@ -8,7 +8,7 @@
 // re-evaluated from the velocities in registers instead of being stored.
 //   k_src_fused : (v_r, v_phi)   -> (v_r_b, v_phi_b)   S1 + S2
 //   k_av_fused  : (v_r_b,v_phi_b)-> (v_r, v_phi) [,e]  S3 + artificial viscosity (+ T range)
-//   k_visc_fused: (v_r, v_phi)   -> (v_r_b, v_phi_b)   stress tensor + viscous update [+ Q+]
+//   k_visc_fused: (v_r, v_phi)   -> (v_r_b, v_phi_b)   stress tensor + viscous update [+ Q+, SubStep3]
 // Row ranges are those of the individual loops; rows outside a range are copied through.
 
 // SourceEuler.cpp:325-428 momentum_update_radial + momentum_update_azimuthal
@@ -235,7 +235,7 @@ template <bool ROWU> __global__ void k_visc_fused(const Dev P)
                 qplus += q;
             }
         }
-        P.qplus[IDX(i, j)] = qplus;
-        P.qminus[IDX(i, j)] = 0.0;
+        // SubStep3 on this cell (cell-local: Q+, Sigma, e, H of the cell; k_visc_fused itself never reads e)
+        substep3_cell(P, i, j, qplus, 0.0, 2);
     }
 }

@@ -642,9 +642,9 @@ __device__ __forceinline__ Cooling cooling_terms(const Dev &P, int i, int j, int
 // SourceEuler.cpp:1000-1048: energy update of SubStep3 (update_energy != 0) or only the
 // alpha rescaling of compute_heating_cooling_for_CFL (:1520-1545)
 // update_energy = 2: followed by SetTemperatureFloorCeilValues on all rings (k_temperature_range) in the same launch
-template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
+// one cell of it; qplus_in / qminus_in: the heating and cooling rates found so far
+__device__ __forceinline__ void substep3_cell(const Dev &P, int i, int j, double qplus_in, double qminus_in, int update_energy)
 {
-    CELL(0, P.nr);
     if (i < 1 || i >= P.nr - 1) { // SubStep3 itself runs on rings [1, Nr-1)
         if (update_energy == 2)
             P.energy[IDX(i, j)] = clamp_energy(P, P.energy[IDX(i, j)], P.sigma[IDX(i, j)]);
@@ -656,8 +656,8 @@ template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
     const double energy = P.energy[IDX(i, j)];
     const double alpha = substep3_alpha(P, H, sigma, energy);
     const Cooling cool = cooling_terms(P, i, j, IDX(i, j), sigma, energy, H);
-    const double Qplus = (P.qplus[IDX(i, j)] + cool.qplus_star) / alpha;
-    double Qminus = (P.qminus[IDX(i, j)] + cool.qminus) / alpha;
+    const double Qplus = (qplus_in + cool.qplus_star) / alpha;
+    double Qminus = (qminus_in + cool.qminus) / alpha;
     if (update_energy) {
         double energy_new = energy + dt * (Qplus - Qminus);
         const double SigmaFloor = 10.0 * P.sigma0_val * P.sigma_floor_rel;
@@ -673,4 +673,10 @@ template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
     }
     P.qplus[IDX(i, j)] = Qplus;
     P.qminus[IDX(i, j)] = Qminus;
+}
+template <bool ROWU> __global__ void k_substep3(const Dev P, int update_energy)
+{
+    CELL(0, P.nr);
+    const bool inner = i >= 1 && i < P.nr - 1;
+    substep3_cell(P, i, j, inner ? P.qplus[IDX(i, j)] : 0.0, inner ? P.qminus[IDX(i, j)] : 0.0, update_energy);
 }

@@ -281,11 +281,13 @@ __device__ __forceinline__ double ring_sum_vphi(const Dev &P, int i, int lane, c
 // Nshift of a ring from its mean (ComputeConstantResidual, :207-236)
 __device__ __forceinline__ double ring_ntilde(const Dev &P, int i, double mean, double dt) { return mean * P.InvRmed[i] * dt * P.invdphi; }
 
-__global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, const double *part, int nparts, int pstride)
+// (vb: the block's index among the ring-mean blocks of its launch; any 256-thread block shape)
+__device__ __forceinline__ void ring_mean_block(const Dev &P, int vb, int with_shift, const double *part, int nparts, int pstride)
 {
     __shared__ int s_nshift[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + w);
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int i = __builtin_amdgcn_readfirstlane(vb * 4 + w);
     const bool active = i < P.nr;
     const double dt = with_shift ? P.clk->dt : 1.0;
     int my_shift = 0;
@@ -344,6 +346,21 @@ __global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, 
     dd = dd > nphi / 2 ? nphi - dd : dd;
     if (dd > 1 && lane == 0)
         P.shift_jump[0] = SHIFT_SEQ(P.clk);
+}
+__global__ void __launch_bounds__(256) k_ring_mean(const Dev P, int with_shift, const double *part, int nparts, int pstride)
+{
+    ring_mean_block(P, blockIdx.x, with_shift, part, nparts, pstride);
+}
+// The two independent first kernels of the unfused Transport() in one launch (narrow rings, where every launch is a
+// visible share of the step): blocks [0, gx gy) do the radial sweep, the (nr + 3) / 4 blocks behind them the ring
+// means, shifts and uniform residuals.
+template <bool ROWU> __global__ void __launch_bounds__(256) k_transport_radial_means(const Dev P, int gx, int gy, int rows, const double *part,
+                                                                                    int nparts, int pstride)
+{
+    if ((int)blockIdx.x < gx * gy)
+        transport_radial_block<ROWU>(P, blockIdx.x, gx, gx * gy, rows);
+    else
+        ring_mean_block(P, (int)blockIdx.x - gx * gy, 1, part, nparts, pstride);
 }
 
 // Upwind star state at azimuthal interface k (between cells k-1 and k),
