@@ -97,8 +97,10 @@ __device__ __forceinline__ bool cfl_last_workgroup(int *tickets, int b, int nb);
 // interior while the ghost rings are on the wire and the rings next to them after the unpack (fcpt_cfl_begin).
 // finalize: 0 = partial maxima only (the interior rings ahead of the ghost exchange), 1 + apply_policy = the last
 // workgroup also folds them (cfl_fold over all nr rings)
-template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings(const Dev P, double *part, int r1, int n1, int r2, int finalize)
+// NT threads per ring, MAXP pairs of cells per thread (NT x MAXP x 2 >= Nphi)
+template <bool ADI, int MAXP, int NT = 256> __global__ void __launch_bounds__(NT) k_cfl_rings(const Dev P, double *part, int r1, int n1, int r2, int finalize)
 {
+    constexpr int NW = NT / 64;
     const int b = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
     const int i = b < n1 ? r1 + b : r2 + (b - n1);
     const int nphi = P.nphi, npair = nphi >> 1;
@@ -108,7 +110,7 @@ template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings
     double acc = 0.0, acc2 = 0.0;
 #pragma unroll
     for (int n = 0; n < MAXP; ++n) {
-        const int p = t + n * 256;
+        const int p = t + n * NT;
         va[n] = D2{0.0, 0.0};
         if (p < npair)
             va[n] = *(const D2 *)(P.vazi + row + 2 * p);
@@ -121,11 +123,15 @@ template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings
     acc += acc2;
     for (int off = 32; off > 0; off >>= 1)
         acc += __shfl_down(acc, off, 64);
-    __shared__ double s_w[4], s_m[4];
+    __shared__ double s_w[NW], s_m[NW];
     if ((t & 63) == 0)
         s_w[t >> 6] = acc;
     __syncthreads();
-    const double mean = ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) / (double)nphi;
+    double ring_sum = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]); // (the 256-thread order; more wavefronts append pairwise)
+#pragma unroll
+    for (int q = 4; q < NW; q += 4)
+        ring_sum += (s_w[q] + s_w[q + 1]) + (s_w[q + 2] + s_w[q + 3]);
+    const double mean = ring_sum / (double)nphi;
     if (t == 0)
         P.vmean[i] = mean;
     double s = 0.0;
@@ -144,7 +150,7 @@ template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings
         const double sub = P.fast_transport ? mean : 0.0;
 #pragma unroll
         for (int n = 0; n < MAXP; ++n) {
-            const int p = t + n * 256;
+            const int p = t + n * NT;
             if (p < npair) {
                 const int j = 2 * p;
                 const D2 r0 = *(const D2 *)(P.vrad + row + j), r1 = *(const D2 *)(P.vrad + row + nphi + j);
@@ -210,8 +216,13 @@ template <bool ADI, int MAXP> __global__ void __launch_bounds__(256) k_cfl_rings
     if ((t & 63) == 0)
         s_m[t >> 6] = s;
     __syncthreads();
-    if (t == 0)
-        part[i] = dmax(dmax(s_m[0], s_m[1]), dmax(s_m[2], s_m[3]));
+    if (t == 0) {
+        double m = dmax(dmax(s_m[0], s_m[1]), dmax(s_m[2], s_m[3]));
+#pragma unroll
+        for (int q = 4; q < NW; ++q)
+            m = dmax(m, s_m[q]);
+        part[i] = m;
+    }
     if (finalize && cfl_last_workgroup(P.cfl_tickets, blockIdx.x, gridDim.x))
         cfl_fold(P, part, P.nr, finalize - 1);
 }

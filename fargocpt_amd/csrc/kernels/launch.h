@@ -663,6 +663,22 @@ static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, int f
     if (n1 + n2 <= 0)
         return;
     const bool wide = P.nphi > 512 * CFL_MAXP;
+#ifdef FCPT_CFL_NT /* tuning builds: NT threads per ring, CFL_MAXP * 256 / NT pairs each (Nphi <= 4096) */
+    if (!wide) {
+        if (P.adiabatic)
+            KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<true, CFL_MAXP * 256 / FCPT_CFL_NT, FCPT_CFL_NT>), dim3(n1 + n2), dim3(FCPT_CFL_NT), P, P.cfl_part, r1, n1, r2, finalize);
+        else
+            KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, CFL_MAXP * 256 / FCPT_CFL_NT, FCPT_CFL_NT>), dim3(n1 + n2), dim3(FCPT_CFL_NT), P, P.cfl_part, r1, n1, r2, finalize);
+        return;
+    }
+#endif
+    // isothermal rings of 2049 .. 4096 cells: 1024 threads with two cell pairs each instead of 256 with eight (all of
+    // a thread's loads in flight at once: 37 -> 33 us at 2048 x 4096, two A/B pairs, profiles/r03_ab_cfl_threads.txt;
+    // the ideal-EOS instantiation -- five grids, 4.5 TB/s -- is indifferent to it: 74.5 us either way)
+    if (!P.adiabatic && !wide && P.nphi > 2048) {
+        KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, CFL_MAXP / 4, 1024>), dim3(n1 + n2), dim3(1024), P, P.cfl_part, r1, n1, r2, finalize);
+        return;
+    }
     if (P.adiabatic && wide)
         KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<true, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
     else if (P.adiabatic)
