@@ -68,7 +68,7 @@ OWN_DOUBLES = {
     "k_source_march_adi": (10, 10),       # Sigma, v_r, v_phi, e -> v_r', v_phi', e', Q+, Q-, Q+ - Q-
     "k_source_march_adi_wide": (10, 10),
     "k_src_fused": (7, 7), "k_av_fused": (5, 7), "k_visc_fused": (6, 7),
-    "k_cfl_rings": (2, 6), "k_cfl_cells": (4, 7), "k_pressure": (3, 2), "k_potential": (2, 2), "k_ring_mean": (1, 1),
+    "k_cfl_rings": (2, 6), "k_cfl_rings_bc": (2, 6), "k_cfl_cells": (4, 7), "k_pressure": (3, 2), "k_potential": (2, 2), "k_ring_mean": (1, 1),
 }
 
 

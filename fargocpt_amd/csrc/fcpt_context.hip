@@ -64,6 +64,7 @@ void options_from_environment(Options &o)
     o.inline_potential = 1;
     o.cfl_thermal = 0; // measured: the kernel that stores the terms spills (28 B) and loses more than the CFL pass gains
     o.bc_fold = 1;
+    o.bc_in_cfl = 1;
     o.comm_overlap = 0;
     o.comm_loopback = 0;
     o.graph_steps = -1;

@@ -54,6 +54,9 @@ struct fcpt_ctx {
     double policy_dt_host = -1.0; // the last kick left the energy in energy_b (marching source step, ideal EOS)
     bool march_source = true;
     bool stepped = false; // fcpt_step ran since the last fcpt_post
+    // fcpt_run_steps (single slab): the final boundary call of the step just taken has not been launched yet -- the next
+    // iteration's CFL launch carries it (k_cfl_rings_bc), or flush_deferred_boundary() does.  Never set when the function returns.
+    bool bc_deferred = false;
     bool cfl_interior = false; // fcpt_cfl_begin evaluated the interior rings of the current state
     bool damp_any = false;     // this slab holds rings of a damping zone
     double *thermal_grid = nullptr; // storage of Dev::cfl_thermal (the view's pointer is null when the option is off)
@@ -145,7 +148,8 @@ void apply_boundary(fcpt_ctx *c, bool final);
 void ensure_pressure(fcpt_ctx *c);
 void enqueue_cfl(fcpt_ctx *c, int apply_policy);
 void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool split = false);
-void enqueue_post(fcpt_ctx *c);
+void enqueue_post(fcpt_ctx *c, bool may_defer_boundary = false);
+void flush_deferred_boundary(fcpt_ctx *c);
 // fcpt_exchange.hip
 int enqueue_exchange(fcpt_ctx *c);
 int enqueue_cfl_allreduce(fcpt_ctx *c);

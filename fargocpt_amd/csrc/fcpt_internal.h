@@ -151,6 +151,7 @@ struct Options {
     int inline_potential;   // 0: ideal EOS: k_potential every step instead of the evaluation inside k_source_march_adi
     int cfl_thermal;        // 1: ideal EOS: the transport stores the cell-local CFL terms, the CFL kernel reads 3 grids, not 6
     int bc_fold;            // 0: the pre-transport boundary call as its own launch instead of inside the source march
+    int bc_in_cfl;          // 0: fcpt_run_steps launches the final boundary call of a step by itself instead of inside the next CFL launch
     int comm_overlap;       // fcpt_exchange: transfers on the library's communication stream under the interior CFL
     int comm_loopback;      // rehearsal on one GPU: both "neighbours" of the slab are the slab itself
     int graph_steps;        // fcpt_run_steps: replay a captured hipGraph of one step (launch-bound narrow grids)
@@ -159,7 +160,7 @@ struct Options {
 #define FCPT_OPTION_NAMES                                                                                        \
     X(transport_fused) X(transport_rows) X(source_rows) X(theta_rows) X(transport_fallback) X(transport_split)    \
     X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_split)   \
-    X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(comm_overlap) X(comm_loopback) X(graph_steps) X(profile_stride)
+    X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(bc_in_cfl) X(comm_overlap) X(comm_loopback) X(graph_steps) X(profile_stride)
 
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.
 struct Dev {

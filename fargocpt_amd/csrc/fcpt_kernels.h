@@ -21,7 +21,7 @@ enum KernelId {
     KID_TRANSPORT_FUSED, KID_MASSFLOW, KID_CFL_RINGS, KID_TRANSPORT_FALLBACK, KID_EXCHANGE_COPY,
     KID_DISK_ON_BODY, KID_VISC_FACTORS, KID_SOURCE_MARCH_ADI, KID_SOURCE_MARCH_ADI_WIDE,
     KID_TRANSPORT_FUSED_THERM, KID_TRANSPORT_FUSED_WIDE, KID_STEP_COOP, KID_ACCEL_ON_GAS,
-    KID_SOURCE_MARCH_ADI_ACC, KID_TRANSPORT_RADIAL_MEANS, KID_COUNT
+    KID_SOURCE_MARCH_ADI_ACC, KID_TRANSPORT_RADIAL_MEANS, KID_CFL_RINGS_BC, KID_COUNT
 };
 static_assert(KID_COUNT <= 64, "fcpt_profile_start selects kernels with a 64-bit mask");
 extern const char *const kKernelNames[KID_COUNT];
@@ -82,6 +82,8 @@ void launch_pressure(const Dev &P, hipStream_t st);
 void launch_temperature(const Dev &P, hipStream_t st);
 void launch_cfl(const Dev &P, int apply_policy, hipStream_t st, bool interior_done = false);
 bool launch_cfl_interior(const Dev &P, hipStream_t st);
+bool cfl_bc_mergeable(const Dev &P);
+void launch_cfl_bc(const Dev &P, int apply_policy, hipStream_t st);
 void launch_clock_set_dt(DevClock *clk, double dt, hipStream_t st);
 void launch_clock_scale_dt(DevClock *clk, int mode, double dt, double factor, hipStream_t st);
 void launch_clock_export_cfl(DevClock *clk, double *out, hipStream_t st);

@@ -211,11 +211,25 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool spl
     c->stepped = true;
 }
 
-void enqueue_post(fcpt_ctx *c)
+void flush_deferred_boundary(fcpt_ctx *c)
+{
+    if (c->bc_deferred) {
+        c->bc_deferred = false;
+        launch_boundary(c->P, c->stream);
+    }
+}
+
+void enqueue_post(fcpt_ctx *c, bool may_defer_boundary)
 {
     join_side(c);
     // the damping of the final boundary call was applied by k_velocities when damp_in_step
-    apply_boundary_view(c, c->P, true, c->P.damp_in_step != 0 && c->stepped);
+    const bool damping_done = c->P.damp_in_step != 0 && c->stepped;
+    // fcpt_run_steps: when the call is nothing but the ghost-ring kernel (no separate damping launches, no derived grids
+    // to refresh behind it) and the next launch of the stream is the one-block-per-ring CFL kernel, that launch carries it
+    if (may_defer_boundary && (damping_done || !c->damp_any) && !(c->P.adiabatic && !c->P.lazy_derived) && cfl_bc_mergeable(c->P))
+        c->bc_deferred = true;
+    else
+        apply_boundary_view(c, c->P, true, damping_done);
     c->stepped = false;
     if (c->P.adiabatic && !c->P.lazy_derived) {
         launch_derived(c->P, c->stream);
@@ -230,7 +244,13 @@ void enqueue_cfl(fcpt_ctx *c, int apply_policy)
     join_side(c);
     c->P.cfl_thermal_on = c->thermal_valid ? 1 : 0;
     c->P.qdiff_on = c->qdiff_valid ? 1 : 0;
-    launch_cfl(c->P, apply_policy, c->stream, c->cfl_interior);
+    if (c->bc_deferred && !c->cfl_interior && cfl_bc_mergeable(c->P)) {
+        c->bc_deferred = false;
+        launch_cfl_bc(c->P, apply_policy, c->stream); // + the final boundary call of the step before
+    } else {
+        flush_deferred_boundary(c);
+        launch_cfl(c->P, apply_policy, c->stream, c->cfl_interior);
+    }
     c->cfl_interior = false;
 }
 
@@ -426,7 +446,7 @@ unsigned launch_flags(const fcpt_ctx *c)
            (c->cfl_interior ? 8u : 0u) | (c->kick_energy_b ? 16u : 0u) | (c->fused_source ? 32u : 0u) |
            (c->march_source ? 64u : 0u) | (c->has_mid ? 128u : 0u) | (c->join_pending ? 256u : 0u) |
            (c->thermal_valid ? 512u : 0u) | (c->ghosts_unknown ? 1024u : 0u) | (c->qdiff_valid ? 2048u : 0u) |
-           ((unsigned)c->src_parts << 12);
+           (c->bc_deferred ? 4096u : 0u) | ((unsigned)c->src_parts << 13);
 }
 bool graph_wanted(const fcpt_ctx *c)
 {
@@ -442,7 +462,7 @@ void enqueue_device_step(fcpt_ctx *c)
 {
     enqueue_cfl(c, 1);
     enqueue_step(c, true, 0.0, c->d.cfl <= 0.8);
-    enqueue_post(c);
+    enqueue_post(c, c->P.opt.bc_in_cfl != 0); // (the boundary call may ride in the next iteration's CFL launch)
 }
 // capture `cycle` steps; true if the host-side state is back where it started (the graph can be replayed)
 bool capture_graph(fcpt_ctx *c, int cycle)
@@ -481,7 +501,8 @@ bool capture_graph(fcpt_ctx *c, int cycle)
         c->thermal_valid = f0 & 512u;
         c->ghosts_unknown = f0 & 1024u;
         c->qdiff_valid = f0 & 2048u;
-        c->src_parts = (int)(f0 >> 12);
+        c->bc_deferred = f0 & 4096u;
+        c->src_parts = (int)(f0 >> 13);
         drop_graph(c);
         return false;
     }
@@ -550,11 +571,18 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
         // dt never leaves the device: CFL reduction -> policy kernel -> step -> post
         if (graph_wanted(c) && nsteps >= 8) {
             join_side(c);
-            if (c->graph_exec && (std::memcmp(&c->graph_P, &c->P, sizeof(Dev)) != 0 || c->graph_flags != launch_flags(c)))
-                drop_graph(c); // bodies, options, pointers or lazy flags changed since the capture
-            if (!c->graph_exec) {
-                for (; n < 2; ++n) // the lazily evaluated grids settle within two steps
-                    enqueue_device_step(c);
+            // A captured cycle is replayed while the host-side state that decided its launches (the whole Dev view, the
+            // lazy-evaluation flags) is what it was at capture: bodies, options, uploads change it for good; the parity
+            // of the transport's ping-pong and the boundary call that rides in the next CFL launch (deferred inside
+            // this function only) are put back by one or two plain steps -- the same two that let the lazily evaluated
+            // grids settle before the first capture.
+            auto valid = [&] {
+                return c->graph_exec && std::memcmp(&c->graph_P, &c->P, sizeof(Dev)) == 0 && c->graph_flags == launch_flags(c);
+            };
+            for (int lead = 0; lead < 2 && !valid(); ++lead, ++n)
+                enqueue_device_step(c);
+            if (!valid()) {
+                drop_graph(c);
                 if (!capture_graph(c, 2) && !capture_graph(c, 4))
                     c->graph_failed = true;
             }
@@ -567,6 +595,7 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
         }
         for (; n < nsteps; ++n)
             enqueue_device_step(c);
+        flush_deferred_boundary(c); // the last step's boundary call has no CFL launch to ride in
         HIPCHK(hipGetLastError());
     } else {
         const double t_final = (double)c->d.nsnapshots * c->d.nmonitor * c->d.monitor_timestep;

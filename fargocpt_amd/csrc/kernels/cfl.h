@@ -98,11 +98,12 @@ __device__ __forceinline__ bool cfl_last_workgroup(int *tickets, int b, int nb);
 // finalize: 0 = partial maxima only (the interior rings ahead of the ghost exchange), 1 + apply_policy = the last
 // workgroup also folds them (cfl_fold over all nr rings)
 // NT threads per ring, MAXP pairs of cells per thread (NT x MAXP x 2 >= Nphi)
-template <bool ADI, int MAXP, int NT = 256> __global__ void __launch_bounds__(NT) k_cfl_rings(const Dev P, double *part, int r1, int n1, int r2, int finalize)
+// (P BY VALUE, as a kernel's own argument: with `const Dev &P` the scheduler hoists the loads of all eight cell pairs of
+//  the 256-thread form -- 224 instead of 100 registers, two instead of four wavefronts per SIMD -- and the ideal-EOS
+//  launch takes 97 instead of 74 us: occupancy beats loads in flight per thread here)
+template <bool ADI, int MAXP, int NT> __device__ __forceinline__ void cfl_ring_block(const Dev P, double *part, const int i)
 {
     constexpr int NW = NT / 64;
-    const int b = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
-    const int i = b < n1 ? r1 + b : r2 + (b - n1);
     const int nphi = P.nphi, npair = nphi >> 1;
     const int t = threadIdx.x;
     const size_t row = (size_t)i * nphi;
@@ -223,8 +224,54 @@ template <bool ADI, int MAXP, int NT = 256> __global__ void __launch_bounds__(NT
             m = dmax(m, s_m[q]);
         part[i] = m;
     }
+}
+#define CFL_RINGS_ATTR __launch_bounds__(NT)
+template <bool ADI, int MAXP, int NT = 256> __global__ void CFL_RINGS_ATTR k_cfl_rings(const Dev P, double *part, int r1, int n1, int r2, int finalize)
+{
+    const int b = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
+    const int i = b < n1 ? r1 + b : r2 + (b - n1);
+    cfl_ring_block<ADI, MAXP, NT>(P, part, i);
     if (finalize && cfl_last_workgroup(P.cfl_tickets, blockIdx.x, gridDim.x))
         cfl_fold(P, part, P.nr, finalize - 1);
+}
+// condition_cfl of step n + 1 and the final boundary call of step n (boundary_conditions.cpp:65-114 without its damping,
+// which the transport kernel applied) in ONE launch -- the device-resident loop of fcpt_run_steps, where the two are
+// neighbours in the stream.  The boundary kernel is a chain of dependent loads of 5-7 us on its own; here its nbc
+// workgroups (one column per thread) are the first of the grid and run under the CFL terms of the rings that read
+// nothing it writes.  Four rings do: 0 and nr-1 (their <v_phi> enters the shear limit) and 1 and nr-2 (v_r rows 1 and
+// nr-1).  Their workgroups are the last of the grid and wait until the boundary workgroups -- running or done by then,
+// never waiting for anything themselves -- have published this step's stamp (sequence number as for the shift-jump
+// flag: nothing is ever reset by a kernel).  flag[1]: arrivals of the boundary workgroups, flag[3]: the stamp.
+template <bool ADI, int MAXP, int NT = 256> __global__ void CFL_RINGS_ATTR k_cfl_rings_bc(const Dev P, double *part, int nbc)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    int *flag = P.shift_jump;
+    const int seq = SHIFT_SEQ(P.clk);
+    if (b < nbc) {
+        const int j = b * NT + t;
+        if (j < P.nphi)
+            boundary_column(P, j, 3);
+        __syncthreads();
+        if (t == 0) {
+            __threadfence(); // the workgroup's ghost rings are visible device-wide before it reports in
+            if (__hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nbc - 1) {
+                __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(flag + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    const int nr = P.nr, nfree = nr - 4, q = b - nbc;
+    int i;
+    if (q < nfree) {
+        i = 2 + xcd_block(q, nfree);
+    } else {
+        const int d = q - nfree;
+        i = d == 0 ? 0 : (d == 1 ? 1 : (d == 2 ? nr - 2 : nr - 1));
+        while (__hip_atomic_load(flag + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq)
+            __builtin_amdgcn_s_sleep(2);
+    }
+    cfl_ring_block<ADI, MAXP, NT>(P, part, i);
 }
 // The last step of the reduction by one workgroup: fold the partial maxima, add the FARGO shear limit, leave the
 // result in the device clock (and apply the CalculateTimeStep policy for device-resident loops).

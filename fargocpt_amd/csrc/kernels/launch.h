@@ -13,7 +13,7 @@ const char *const kKernelNames[KID_COUNT] = {
     "k_transport_theta_march", "k_transport_fused", "k_massflow", "k_cfl_rings", "k_transport_fallback",
     "k_exchange_copy", "k_disk_on_body", "k_visc_factors", "k_source_march_adi", "k_source_march_adi_wide",
     "k_transport_fused_therm", "k_transport_fused_wide", "k_step_coop", "k_accel_on_gas", "k_source_march_adi_acc",
-    "k_transport_radial_means"};
+    "k_transport_radial_means", "k_cfl_rings_bc"};
 
 thread_local Profiler *g_prof = nullptr;
 
@@ -687,6 +687,33 @@ static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, int f
         KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, 2 * CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
     else
         KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, CFL_MAXP>), dim3(n1 + n2), dim3(256), P, P.cfl_part, r1, n1, r2, finalize);
+}
+// launch_cfl with the final boundary call of the previous step inside the ring launch (see k_cfl_rings_bc); the caller
+// has checked cfl_bc_mergeable()
+// (worth it only where the ring launch is several rounds of workgroups long -- measured, three / two A/B pairs each,
+//  profiles/r03_ab_bc_in_cfl.txt: 2048 x 4096 isothermal 0.3311 against 0.3343 ms per step, ideal EOS 0.511 against
+//  0.514; on a grid whose workgroups are all resident at once the four waiting ones start with the rest and spin:
+//  512 x 1536 0.0755 against 0.0725, 1024 x 3072 ideal 0.223 against 0.222)
+bool cfl_bc_mergeable(const Dev &P) { return cfl_by_rings(P) && P.nr >= 8 && (long long)P.nr * P.nphi >= (1ll << 22); }
+void launch_cfl_bc(const Dev &P, int apply_policy, hipStream_t st)
+{
+    const bool wide = P.nphi > 512 * CFL_MAXP;
+#define CFLBC(ADI_, MAXP_, NT_)                                                                                              \
+    KLAUNCH(KID_CFL_RINGS_BC, (k_cfl_rings_bc<ADI_, MAXP_, NT_>), dim3((P.nphi + NT_ - 1) / NT_ + P.nr), dim3(NT_), P, P.cfl_part, \
+            (P.nphi + NT_ - 1) / NT_)
+    if (!P.adiabatic && !wide && P.nphi > 2048) {
+        CFLBC(false, CFL_MAXP / 4, 1024);
+    } else if (P.adiabatic && wide) {
+        CFLBC(true, 2 * CFL_MAXP, 256);
+    } else if (P.adiabatic) {
+        CFLBC(true, CFL_MAXP, 256);
+    } else if (wide) {
+        CFLBC(false, 2 * CFL_MAXP, 256);
+    } else {
+        CFLBC(false, CFL_MAXP, 256);
+    }
+#undef CFLBC
+    KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
 }
 // phase 1 of a split CFL: the interior rings only (returns false when the one-block-per-ring kernel does not apply)
 bool launch_cfl_interior(const Dev &P, hipStream_t st)
