@@ -151,7 +151,7 @@ struct Options {
     int inline_potential;   // 0: ideal EOS: k_potential every step instead of the evaluation inside k_source_march_adi
     int cfl_thermal;        // 1: ideal EOS: the transport stores the cell-local CFL terms, the CFL kernel reads 3 grids, not 6
     int bc_fold;            // 0: the pre-transport boundary call as its own launch instead of inside the source march
-    int bc_in_cfl;          // 0: fcpt_run_steps launches the final boundary call of a step by itself instead of inside the next CFL launch
+    int bc_in_cfl;          // 0: fcpt_run_steps launches the final boundary call of a step by itself instead of inside the next CFL launch (1: on grids of >= 4M cells, 2: on any grid)
     int comm_overlap;       // fcpt_exchange: transfers on the library's communication stream under the interior CFL
     int comm_loopback;      // rehearsal on one GPU: both "neighbours" of the slab are the slab itself
     int graph_steps;        // fcpt_run_steps: replay a captured hipGraph of one step (launch-bound narrow grids)

@@ -694,7 +694,10 @@ static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, int f
 //  profiles/r03_ab_bc_in_cfl.txt: 2048 x 4096 isothermal 0.3311 against 0.3343 ms per step, ideal EOS 0.511 against
 //  0.514; on a grid whose workgroups are all resident at once the four waiting ones start with the rest and spin:
 //  512 x 1536 0.0755 against 0.0725, 1024 x 3072 ideal 0.223 against 0.222)
-bool cfl_bc_mergeable(const Dev &P) { return cfl_by_rings(P) && P.nr >= 8 && (long long)P.nr * P.nphi >= (1ll << 22); }
+bool cfl_bc_mergeable(const Dev &P)
+{
+    return cfl_by_rings(P) && P.nr >= 8 && ((long long)P.nr * P.nphi >= (1ll << 22) || P.opt.bc_in_cfl == 2); // (2: tests)
+}
 void launch_cfl_bc(const Dev &P, int apply_policy, hipStream_t st)
 {
     const bool wide = P.nphi > 512 * CFL_MAXP;

@@ -816,3 +816,43 @@ def test_half_limiter_edge_cases(product):
     assert (got[zero] == 0.0).all()
     ok = fin & (np.abs(want) > 1e-290)           # (results in the denormal range carry fewer bits in either form)
     assert np.abs(got[ok] / want[ok] - 1.0).max() <= 4e-15   # v_rcp_f64 + one Newton step + the product: a few ulp
+
+
+@pytest.mark.parametrize("case", ["iso_96x512", "ideal_64x384", "iso_graph_40x256"])
+def test_boundary_call_inside_the_cfl_launch(product, case):
+    """fcpt_run_steps on large grids lets the final boundary call of a step ride in the next step's CFL launch
+    (k_cfl_rings_bc: the boundary workgroups first, the four rings that read what they write last, behind a stamp).
+    Forced here on small grids (option bc_in_cfl = 2), with and without hipGraph replay: the same bits as the
+    host-driven loop cfl -> calculate_timestep -> step -> post."""
+    from fargocpt_amd import driver
+    dims = case.split("_")[-1]
+    nr, nphi = (int(x) for x in dims.split("x"))
+    d = setups.planet_disk(product, nr, nphi, adiabatic=case.startswith("ideal"))
+    radii = product.radii(d)
+    fields = product.initial_fields(d.copy(), radii)
+    states = []
+    for mode in ("host", "merged"):
+        ctx = driver.make_context(product, d, fields=fields, radii=radii, bodies=setups.jupiter_bodies(d))
+        ctx.set_option("graph_steps", 1 if "graph" in case else 0)
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        if mode == "host":
+            S.run(23)
+        else:
+            ctx.set_option("bc_in_cfl", 2)
+            names = product.kernel_names()
+            ctx.profile_start([names.index("k_cfl_rings_bc"), names.index("k_boundary")], max_launches=64)
+            ctx.run_steps(9)      # profiled: plain launches
+            prof = ctx.profile_stop()
+            # eight of nine boundary calls rode in a CFL launch, the last was flushed (+ the nine pre-transport calls
+            # where the source march does not fold them in)
+            # (k_boundary: the flush, + the first step's pre-transport call after the upload of the state)
+            assert prof["k_cfl_rings_bc"][1] == 8 and prof["k_boundary"][1] in (1, 2, 10, 11), prof
+            ctx.run_steps(14)     # (graph case: two lead steps, captured cycles, the flush)
+            if "graph" in case:
+                assert ctx.get_option("graph_replays") > 0
+        states.append((ctx.state(), ctx.clock.time))
+        ctx.close()
+    assert states[0][1] == states[1][1]
+    for k in states[0][0]:
+        assert np.array_equal(states[0][0][k], states[1][0][k]), k
