@@ -417,17 +417,21 @@ def main():
         for _ in range(2):
             parity_ctx.calculate_timestep(parity_ctx.cfl())
         parity_ctx.run_steps(PARITY_STEPS)
-    settle_steps = leg.settle()
-
-    # ---- warm-up, with a per-kernel calibration pass to find the dominant kernel --
-    cal = min(3, max(1, args.warmup))
+    # ---- calibration: a per-kernel pass (HIP events around every launch of three steps) finds the dominant kernel.
+    # It comes BEFORE the settle steps: fcpt_profile_stop synchronises and creates events, a pause of milliseconds on
+    # the host during which the GPU idles and its clocks sag -- with the calibration between the settle steps and the
+    # timed region (round 2) a 20-step region read 3 % above the blocks that followed it.  The events of the timed
+    # region are created here too.
+    cal = 3
     ctx.profile_start(None, max_launches=64 * cal)
     leg.run(cal)
     prof = ctx.profile_stop()
     dominant = max(prof, key=lambda k: prof[k][0])
     names = lib.kernel_names()
-    if args.warmup > cal:
-        leg.run(args.warmup - cal)
+    ctx.profile_start([names.index(dominant)], max_launches=args.steps + 8)
+    ctx.profile_stop()
+    settle_steps = leg.settle() + cal
+    leg.run(args.warmup)
 
     # ---- timed region ---------------------------------------------------------
     # HIP events around the dominant kernel, live in the timed region (roofline.kernel_ms): an event pair costs ~3 us of
@@ -499,8 +503,8 @@ def main():
             "untimed_steps_before_timed_region": args.warmup + settle_steps,
             "settle_protocol": f">= {SETTLE_STEPS} steps and >= {SETTLE_MS:.0f} ms of this workload on the timed context before "
                                "the warm-up; the same for every row of `configs` and for `strong_scaling`",
-            "untimed_other": "2 CFL + CalculateTimeStep calls of sim::init; the first min(3, W) warm-up steps carry "
-                             "HIP-event pairs around every kernel (calibration of the dominant kernel)"
+            "untimed_other": "2 CFL + CalculateTimeStep calls of sim::init; three calibration steps with HIP-event pairs "
+                             "around every kernel (they find the dominant kernel) ahead of the settle steps"
                              + (f"; before the settle steps, {PARITY_STEPS} steps of the same workload on a second context "
                                 "(device half of cpu_baseline's parity check), queued on the same stream"
                                 if parity_ctx is not None else ""),

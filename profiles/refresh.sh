@@ -17,8 +17,8 @@ bash $R/profiles/run_pmc.sh $O/pmc_ideal --steps 8 --warmup 2 --eos ideal > $O/p
 cd $R
 python3 profiles/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
 python3 profiles/pmc_summary.py $O/pmc_ideal > $O/pmc_ideal_summary.txt 2>&1
-python3 profiles/make_pmc_json.py $O/pmc profiles/r02_pmc_summary.txt 2048x4096 isothermal > $O/pmc_latest.json
-python3 profiles/make_pmc_json.py $O/pmc_ideal profiles/r02_ideal_eos_pmc_summary.txt 2048x4096 ideal > $O/pmc_latest_ideal.json
+python3 profiles/make_pmc_json.py $O/pmc profiles/r03_pmc_summary.txt 2048x4096 isothermal > $O/pmc_latest.json
+python3 profiles/make_pmc_json.py $O/pmc_ideal profiles/r03_ideal_eos_pmc_summary.txt 2048x4096 ideal > $O/pmc_latest_ideal.json
 find $O/pmc $O/pmc_ideal -name "*kernel_trace.csv" -delete
 find $O/pmc $O/pmc_ideal -name "*counter_collection.csv" -delete
 echo "[4] bench lines"
