@@ -149,3 +149,31 @@ def test_library_comm_errors(product):
     with pytest.raises(B.FcptError, match="unknown option"):
         ctx.set_option("no_such_switch", 1)
     ctx.close()
+
+
+def test_bench_n_rank_line_rehearsed_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2 --transport host`: every code path of the N-rank bench line -- the launcher, the slab
+    contexts, the communicator hand-shake, the settle protocol with its all-reduced stop decision, barriers and
+    max-over-ranks timing, the strong-scaling row (BASELINE config 4) and the cross-rank check of ghost rows and clocks --
+    with the ranks sharing this box's GPU: gloo process group + the library's host-staged transport instead of RCCL
+    (which refuses two ranks on one device).  The line says that it is a rehearsal, not a scaling number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FCPT_BENCH_SETTLE_STEPS"], env["FCPT_BENCH_SETTLE_MS"] = "10", "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--transport", "host", "--steps", "6",
+                        "--warmup", "2", "--nr", "64", "--nphi", "512", "--settle-blocks", "1"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["grid"] == [128, 512]
+    assert rec["config"]["ghost_rings_and_clock_consistent"] is True and rec["config"]["finite"] is True
+    assert "NOT a scaling number" in rec["config"]["rehearsal"] and "host-staged" in rec["config"]["communication"]
+    assert len(rec["ms_per_step_per_rank"]) == 2 and rec["roofline"]["frac"] <= 1.0
+    s = rec["strong_scaling"]
+    assert s["scaling"] == "strong" and s["grid"] == [2048, 6144] and s["ghost_rings_and_clock_consistent"] is True
+    assert s["value"] == pytest.approx(2048 * 6144 / (s["ms_per_step"] * 1e-3), rel=1e-9)
