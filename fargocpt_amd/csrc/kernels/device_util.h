@@ -104,6 +104,13 @@ __device__ __forceinline__ double fast_rsqrt(double x)
     y = y * fma(-h * y, y, 1.5);
     return y;
 }
+// One Newton step on v_rsq_f64: ~1e-15 relative, for roots whose error reaches the state scaled by dt (the smoothed
+// distance of the inline potential, the sound speed that enters nu and H of the viscous terms)
+__device__ __forceinline__ double fast_rsqrt1(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    return y * fma(-(0.5 * x) * y, y, 1.5);
+}
 // exp(x) for the compression heating of the marching source step (SourceEuler.cpp:459-493), where the argument
 // -(gamma - 1) dt div v is bounded by the CFL condition and almost always tiny.  While every lane of the wavefront
 // has |x| < 1/16 the degree-9 Taylor polynomial is exact to 2.5e-19 relative (nine FMAs; the library routine costs

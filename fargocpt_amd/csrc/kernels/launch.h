@@ -407,7 +407,9 @@ void launch_damping(const Dev &P, double *q, double *q0, const double *radius, c
             r.redge, r.tau, is_density);
 }
 
+#ifndef FALLBACK_BLOCKS
 #define FALLBACK_BLOCKS 256 /* grid of the idle in-stream fallback kernels */
+#endif
 // one radial sweep + ring means (T1-T4); only_if: see k_transport_radial
 static void launch_radial(const Dev &P, const int *only_if, hipStream_t st)
 {

@@ -18,6 +18,20 @@
 // Lane validity erodes by one cell per phi-coupled stage: lanes 3..61 of a segment are
 // final, segments advance by MARCH_VALID = 59 cells.  A chunk of MARCH_ROWS output rings
 // needs 5 extra input rings of warm-up.
+// Reciprocals of the source step: every one of them scales a source term that enters the state times dt (pressure
+// gradient / (Sigma + Sigma), viscous and artificial-viscous forces / Sigma, heating rates / alpha ...), so its error
+// reaches the state damped by dt a / v ~ 1e-2 or less: one Newton step on v_rcp_f64 (<= 2e-15 relative, measured:
+// profiles/tools/rcp_accuracy.hip) instead of two.  (The transport's reciprocals act on full-magnitude quantities and
+// keep both steps.)
+#ifndef FAST_RCP_SRC
+#define FAST_RCP_SRC fast_rcp1
+#endif
+// (The same shortcut for the roots -- one Newton step on v_rsq_f64 for the potential's smoothed distance, c_s as
+//  x rsqrt(x) -- was measured too: -0.5 % per step, and the 4x-CFL full-size case against the oracle at 1.005e-10 instead
+//  of inside the 1e-10 bar.  Not taken.)
+#ifndef FAST_RSQRT_SRC
+#define FAST_RSQRT_SRC fast_rsqrt
+#endif
 #define MARCH_VALID 59
 #define MARCH_LO 3
 
@@ -146,7 +160,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
             const double P_m = S_m * R.cs2_m, P_1 = S_1 * R.cs2_m1, Pp_m = Sp_m * R.cs2_m;
             vr1_m = vr0_m;
             if (r >= P.one_no_ghost_vr && r < P.maxmo_no_ghost_vr) {
-                double gradp = 2.0 * fast_rcp(S_m + S_1);
+                double gradp = 2.0 * FAST_RCP_SRC(S_m + S_1);
                 gradp *= (P_m - P_1);
                 gradp *= R.idr_m;
                 const double gradphi = ACC ? -(F_m + F_1) * 0.5 : (F_m - F_1) * R.idr_m;
@@ -158,7 +172,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
             va1_m = va0_m;
             if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
                 const double invdxtheta = R.inv_dxt_m; // 2 / (dphi (Rsup + Rinf))
-                const double gradp = 2.0 * fast_rcp(S_m + Sp_m) * (P_m - Pp_m) * invdxtheta;
+                const double gradp = 2.0 * FAST_RCP_SRC(S_m + Sp_m) * (P_m - Pp_m) * invdxtheta;
                 const double gradphi = ACC ? -(G_m + Fp_m) * 0.5 : (F_m - Fp_m) * invdxtheta;
                 va1_m = va0_m + dt * (-gradp - gradphi);
             }
@@ -192,21 +206,21 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                 const double qpp_p = PREV(qp_1);
                 if (r >= 1 && r < nr - 1) {
                     const double sigma_phi_avg = 0.5 * (S_1 + Sp_1);
-                    va2_1 = va1_1 + 2.0 * dt * (R.inv_rsum_c * fast_rcp(sigma_phi_avg)) * (qp_1 - qpp_p) * P.invdphi;
+                    va2_1 = va1_1 + 2.0 * dt * (R.inv_rsum_c * FAST_RCP_SRC(sigma_phi_avg)) * (qp_1 - qpp_p) * P.invdphi;
                 }
                 if (upd_vr) {
                     const double sigma_r_avg = 0.5 * (S_1 + S_2);
                     const double rm = R.rmed_c, rmm = R.rmed_cm1;
-                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt * fast_rcp(sigma_r_avg) * 2.0 * R.inv_drmed2_c *
+                    vr2_1 = vr1_1 + P.radial_viscosity_factor * dt * FAST_RCP_SRC(sigma_r_avg) * 2.0 * R.inv_drmed2_c *
                                         ((qr_1 * rm - qr_2 * rmm) - 0.5 * (qp_1 + qp_2) * (rm - rmm));
                 }
             } else if (AV == 2) {
                 const double qphi_p = PREV(qp_1);
                 if (upd_vr)
-                    vr2_1 = vr1_1 - dt * 2.0 * fast_rcp(S_1 + S_2) * (qr_1 - qr_2) * R.idr_c;
+                    vr2_1 = vr1_1 - dt * 2.0 * FAST_RCP_SRC(S_1 + S_2) * (qr_1 - qr_2) * R.idr_c;
                 if (r >= P.zero_no_ghost && r < P.max_no_ghost) {
                     const double invdxtheta = R.inv_dxtheta_c;
-                    va2_1 = va1_1 - dt * 2.0 * fast_rcp(S_1 + Sp_1) * (qp_1 - qphi_p) * invdxtheta;
+                    va2_1 = va1_1 - dt * 2.0 * FAST_RCP_SRC(S_1 + Sp_1) * (qp_1 - qphi_p) * invdxtheta;
                 }
             }
         }
@@ -265,14 +279,14 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                 }
                 if (k >= 1 && k < nr - 1) {
                     const double sigma_avg = 0.5 * (S_2 + Sp_2);
-                    const double dVp = dt * R.inv_rmed_k * fast_rcp(sigma_avg) *
+                    const double dVp = dt * R.inv_rmed_k * FAST_RCP_SRC(sigma_avg) *
                                        (R.two_inv_dra2_k * (R.ra1sq_k * trp_1 - R.ra0sq_k * trp_2) +
                                         (tpp_2 - tpp_p) * P.invdphi);
                     va3 = va2_2 + (STAB ? dVp * corr_phi : dVp);
                 }
                 if (k >= P.one_no_ghost_vr && k < P.maxmo_no_ghost_vr) {
                     const double sigma_avg = 0.5 * (S_2 + S_3);
-                    const double dVr = dt * fast_rcp(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
+                    const double dVr = dt * FAST_RCP_SRC(sigma_avg) * P.radial_viscosity_factor * 2.0 * R.inv_rmsum_k *
                                        ((R.rmed_k * trr_2 - R.rmed_km1 * trr_3) * R.idr_k +
                                         (trp_n - trp_2) * P.invdphi - 0.5 * (tpp_2 + tpp_3));
                     vr3 = vr2_2 + (STAB ? dVr * corr_r : dVr);
@@ -386,14 +400,14 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
         const double x = rmed * P.cosphi[j], y = rmed * P.sinphi[j]; // (cache hits after the first ring)
         // (ThicknessSmoothing H)^2 with H = c_s / (sqrt(gamma) Omega_K), c_s^2 = gamma (gamma - 1) e / Sigma: no root needed
         const double hk = P.thickness_smoothing * inv_sqrt_gamma * P.g_inv_omk[r];
-        const double smooth2 = (gg1 * en * fast_rcp(sg)) * (hk * hk);
+        const double smooth2 = (gg1 * en * FAST_RCP_SRC(sg)) * (hk * hk);
         double pot = 0.0;
         for (int k = 0; k < P.nbodies; ++k) {
             const double dx = x - P.bx[k];
             const double dy = y - P.by[k];
             const double dist_2 = dx * dx + dy * dy;
             const double d2s = dist_2 + smooth2;
-            const double inv_d = fast_rsqrt(d2s); // 1 / d_smoothed
+            const double inv_d = FAST_RSQRT_SRC(d2s); // 1 / d_smoothed
             double klahr = 1.0;
             const double r_sm = P.brsm[k];
             if (r_sm > 0.0) {
@@ -459,8 +473,8 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
             F_m = potential_of(crow(m), S_m, e0_m);
         const double Pr_m = gm1 * e0_m, Pr_1 = gm1 * e0_1;
         Sp_m = PREV(S_m);
-        rr_m = fast_rcp(S_m + S_1);
-        rp_m = fast_rcp(S_m + Sp_m);
+        rr_m = FAST_RCP_SRC(S_m + S_1);
+        rp_m = FAST_RCP_SRC(S_m + Sp_m);
         va0n_m = NEXT(va0_m);
         const double va0n_1 = NEXT(va0_1);
         const double Fp_m = ACC ? PREV(G_m) : PREV(F_m);
@@ -523,7 +537,7 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                 e = clamp_energy_fast(P, e, S_1);
             e2_1 = e;
             // V0: recalculate_viscosity on ring m-1
-            const double cs = sqrt(P.gamma * gm1 * e * fast_rcp(S_1));
+            const double cs = sqrt(P.gamma * gm1 * e * FAST_RCP_SRC(S_1));
             H_1 = cs * inv_sqrt_gamma * R.inv_omk_b;
             nu_1 = P.alpha_viscosity ? P.alpha * H_1 * cs : P.nu_const;
             nup_1 = PREV(nu_1);
@@ -624,15 +638,15 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                 if (k < nr) {
                     if (P.heating_viscous && row_va && nu_2 != 0.0) { // viscous_heating
                         const double tau_r_phi = 0.25 * (trp_2 + trp_1 + trp_n + trp_1n);
-                        double q = fast_rcp(2.0 * nu_2 * S_2) * (trr_2 * trr_2 + 2 * (tau_r_phi * tau_r_phi) + tpp_2 * tpp_2);
+                        double q = FAST_RCP_SRC(2.0 * nu_2 * S_2) * (trr_2 * trr_2 + 2 * (tau_r_phi * tau_r_phi) + tpp_2 * tpp_2);
                         q += (2.0 / 9.0) * nu_2 * S_2 * (divv_2 * divv_2);
                         q *= P.heating_viscous_factor;
                         qplus += q;
                     }
                     if (row_va) { // SubStep3, rows [1, Nr-1)
-                        const double bb = P.b_fac * fast_rcp(S_2), b2 = bb * bb; // substep3_alpha
+                        const double bb = P.b_fac * FAST_RCP_SRC(S_2), b2 = bb * bb; // substep3_alpha
                         const double alpha = 1.0 + H_2 * P.alpha_fac * (b2 * b2) * (e * e * e); // alpha_fac = 2 * 4 sigma_SB / c
-                        const double ralpha = fast_rcp(alpha);
+                        const double ralpha = FAST_RCP_SRC(alpha);
                         double tau_eff = 0.0;
                         if (cooling) { // calculate_qminus
                             const Cooling cool = cooling_terms(P, k, j, IDX(k, j), S_2, e, H_2);
