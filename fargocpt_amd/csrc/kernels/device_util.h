@@ -94,6 +94,10 @@ __device__ __forceinline__ double fast_rcp1(double d)
     return fma(x, fma(-d, x, 1.0), x);
 }
 
+// the reciprocals of the marching transport (1 / Sigma of the specific quantities, velocities from momenta)
+#ifndef FAST_RCP_TR
+#define FAST_RCP_TR fast_rcp1
+#endif
 // 1/sqrt(x) from v_rsq_f64 (~2^-26) refined by two Newton steps (~1 ulp): a third of the issue cost of
 // sqrt followed by the IEEE division sequence
 __device__ __forceinline__ double fast_rsqrt(double x)

@@ -645,7 +645,7 @@ __device__ __forceinline__ void theta_pass(int lim, int lsrc_l, int lsrc_r, doub
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         F[c] = (MODE == 0 ? geo_dt * V[c] : gvu) * rho[c];
-        rS[c] = fast_rcp(S[c]);
+        rS[c] = FAST_RCP_TR(S[c]);
     }
     F[C] = SH_NEXT(F[0]);
     auto advect = [&](double (&X)[C]) {
@@ -799,7 +799,7 @@ __device__ __forceinline__ void transport_theta_march_block(const Dev &P, const 
                 double vr = 0.0;
                 if (i != 0)
                     vr = (rmp_prev[c] + Q[1][c]) * fast_rcp(S_prev[c] + S[c]);
-                double va = (lpm + Q[3][c]) * fast_rcp(sm + S[c]) * invr - romega;
+                double va = (lpm + Q[3][c]) * FAST_RCP_TR(sm + S[c]) * invr - romega;
                 double sf = S[c] < P.sigma_floor_abs ? P.sigma_floor_abs : S[c];
                 double e = ADI ? clamp_energy(P, E[c], sf) : 0.0;
                 const int g = row + jout[c];

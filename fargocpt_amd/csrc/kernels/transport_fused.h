@@ -206,7 +206,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
             w[0][3][c] = in_k ? (van + romega) * r : 0.0;             // L+ / Sigma = (v_phi(j+1) + r Omega) r
             w[0][4][c] = in_k ? (o.va[c] + romega) * r : 0.0;         // L- / Sigma
             if (ADI) {
-                w[0][NQ - 1][c] = in_k ? o.en[c] * fast_rcp(o.sg[c]) : 0.0;
+                w[0][NQ - 1][c] = in_k ? o.en[c] * FAST_RCP_TR(o.sg[c]) : 0.0;
                 if (!DIET)
                     er[0][c] = o.en[c];
             }
@@ -357,8 +357,8 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                     const double sm = c == 0 ? s_l : S[c == 0 ? 0 : c - 1];
                     double vr = 0.0;
                     if (i != 0)
-                        vr = (rp[c] + Q[1][c]) * fast_rcp(sp[c] + S[c]);
-                    double va = (lpm + Q[3][c]) * fast_rcp(sm + S[c]) * invr - romega;
+                        vr = (rp[c] + Q[1][c]) * FAST_RCP_TR(sp[c] + S[c]);
+                    double va = (lpm + Q[3][c]) * FAST_RCP_TR(sm + S[c]) * invr - romega;
                     double sf = S[c] < P.sigma_floor_abs ? P.sigma_floor_abs : S[c];
                     double e = ADI ? clamp_energy_fast(P, E[c], sf) : 0.0;
                     const int g = row + jout[c];
