@@ -503,6 +503,8 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         const int v = P.opt.transport_fused;
         CF = v == 0 ? 0 : ((v == 1 || v == 2) && P.nphi >= 128 * v ? v : CF);
     }
+    if ((long long)(P.nr + 1) * P.nphi >= (1ll << 29))
+        CF = 0; // the fused kernel addresses its grids with 32-bit byte offsets (4 GiB each)
     if (CF) {
         Dev Wm = W; // the marching kernels cannot work in place
         Wm.sigma = W.sigA;

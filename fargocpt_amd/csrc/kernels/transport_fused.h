@@ -39,10 +39,18 @@ template <int C> struct TfHalo {
 // reference value and its use sit in one basic block: a load whose use is behind another branch leaves the compiler's
 // s_waitcnt pass with a "maybe pending" register at every later store of the loop, and the pinned prefetch (bottom
 // of the loop) would be waited for on the spot again.
-__device__ __forceinline__ double damp_apply(double X, int type, double ef, const double *ref, int cell, double zero_target)
+// Addresses as 32-bit BYTE offsets from a grid's base: the launcher only takes this kernel for grids below 4 GiB each
+// (2^29 cells), so base (scalar registers) + zext(offset) is the saddr form of global_load / global_store -- one VGPR
+// per address instead of two, and no 64-bit address arithmetic in the vector unit (nine v_lshl_add_u64 per ring before).
+__device__ __forceinline__ double ld_off(const double *base, unsigned off) { return *(const double *)((const char *)base + off); }
+__device__ __forceinline__ void st_off(double *base, unsigned off, double v) { *(double *)((char *)base + off) = v; }
+__device__ __forceinline__ D2 ld2_off(const double *base, unsigned off) { return LD2((const double *)((const char *)base + off)); }
+__device__ __forceinline__ void st2_off(double *base, unsigned off, D2 v) { ST2((double *)((char *)base + off), v); }
+
+__device__ __forceinline__ double damp_apply(double X, int type, double ef, const double *ref, unsigned cell_off, double zero_target)
 {
     if (type == 1) {
-        const double X0 = ref[cell];
+        const double X0 = ld_off(ref, cell_off);
         return (X - X0) * ef + X0;
     }
     if (type != 0)
@@ -163,31 +171,33 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
 #pragma unroll
         for (int c = 0; c < C; ++c)
             o.sg[c] = o.va[c] = o.en[c] = o.vr[c] = 0.0;
-        const size_t row = (size_t)(in_k ? k : 0) * nphi, rowv = (size_t)(in_v ? k + 1 : 0) * nphi;
+        const unsigned row = (unsigned)(in_k ? k : 0) * (unsigned)nphi, rowv = (unsigned)(in_v ? k + 1 : 0) * (unsigned)nphi;
         if (pair_in) {
             if (in_k) {
-                const D2 s2 = LD2(P.sigma + row + jin[0]), v2 = LD2(P.vazi + row + jin[0]);
+                const unsigned ob = (row + (unsigned)jin[0]) * 8u;
+                const D2 s2 = ld2_off(P.sigma, ob), v2 = ld2_off(P.vazi, ob);
                 o.sg[0] = s2.x, o.sg[C - 1] = s2.y, o.va[0] = v2.x, o.va[C - 1] = v2.y;
                 if (ADI) {
-                    const D2 e2 = LD2(P.energy + row + jin[0]);
+                    const D2 e2 = ld2_off(P.energy, ob);
                     o.en[0] = e2.x, o.en[C - 1] = e2.y;
                 }
             }
             if (in_v) {
-                const D2 r2 = LD2(P.vrad + rowv + jin[0]);
+                const D2 r2 = ld2_off(P.vrad, (rowv + (unsigned)jin[0]) * 8u);
                 o.vr[0] = r2.x, o.vr[C - 1] = r2.y;
             }
         } else {
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 if (in_k) {
-                    o.sg[c] = P.sigma[row + jin[c]];
-                    o.va[c] = P.vazi[row + jin[c]];
+                    const unsigned ob = (row + (unsigned)jin[c]) * 8u;
+                    o.sg[c] = ld_off(P.sigma, ob);
+                    o.va[c] = ld_off(P.vazi, ob);
                     if (ADI)
-                        o.en[c] = P.energy[row + jin[c]];
+                        o.en[c] = ld_off(P.energy, ob);
                 }
                 if (in_v)
-                    o.vr[c] = P.vrad[rowv + jin[c]];
+                    o.vr[c] = ld_off(P.vrad, (rowv + (unsigned)jin[c]) * 8u);
             }
         }
     };
@@ -287,7 +297,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
         }
         // ---- update of ring i = m-2, azimuthal passes, velocities -----------------------------
         bool out_on = false, out_pair = false;
-        int out_g[C];
+        unsigned out_g[C]; // byte offsets of the cells this lane stores
         double o_vr[C], o_va[C], o_s[C], o_e[C];
 #pragma unroll
         for (int c = 0; c < C; ++c)
@@ -347,7 +357,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                 const double lp_l = lane_prev(Q[2][C - 1]); // L+ and Sigma of cell j-1
                 const double s_l = lane_prev(S[C - 1]);
                 const double invr = ti.invr, romega = ti.r_omega;
-                const int row = i * nphi;
+                const unsigned row = (unsigned)i * (unsigned)nphi;
                 int jout[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -361,7 +371,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
                     double va = (lpm + Q[3][c]) * FAST_RCP_TR(sm + S[c]) * invr - romega;
                     double sf = S[c] < P.sigma_floor_abs ? P.sigma_floor_abs : S[c];
                     double e = ADI ? clamp_energy_fast(P, E[c], sf) : 0.0;
-                    const int g = row + jout[c];
+                    const unsigned g = (row + (unsigned)jout[c]) * 8u;
                     if (DAMP) {
                         vr = damp_apply(vr, di.tvr, si.ev, W.vrad0, g, 0.0);
                         va = damp_apply(va, di.tva, si.es, W.vazi0, g, 0.0);
@@ -422,38 +432,39 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
 #pragma unroll
             for (int c = 0; c < C; ++c)
                 if (valid[c])
-                    W.cfl_thermal[out_g[c]] = cfl_thermal_term(W, tr, o_s[c], o_e[c], W.qplus[out_g[c]], W.qminus[out_g[c]]);
+                    st_off(W.cfl_thermal, out_g[c], cfl_thermal_term(W, tr, o_s[c], o_e[c], ld_off(W.qplus, out_g[c]), ld_off(W.qminus, out_g[c])));
         }
         if (out_on) {
             if (out_pair) {
                 if (valid[0]) {
-                    ST2(W.vrad + out_g[0], (D2{o_vr[0], o_vr[C - 1]}));
-                    ST2(W.vazi + out_g[0], (D2{o_va[0], o_va[C - 1]}));
-                    ST2(W.sigma + out_g[0], (D2{o_s[0], o_s[C - 1]}));
+                    st2_off(W.vrad, out_g[0], (D2{o_vr[0], o_vr[C - 1]}));
+                    st2_off(W.vazi, out_g[0], (D2{o_va[0], o_va[C - 1]}));
+                    st2_off(W.sigma, out_g[0], (D2{o_s[0], o_s[C - 1]}));
                     if (ADI)
-                        ST2(W.energy + out_g[0], (D2{o_e[0], o_e[C - 1]}));
+                        st2_off(W.energy, out_g[0], (D2{o_e[0], o_e[C - 1]}));
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < C; ++c)
                     if (valid[c]) {
-                        W.vrad[out_g[c]] = o_vr[c];
-                        W.vazi[out_g[c]] = o_va[c];
-                        W.sigma[out_g[c]] = o_s[c];
+                        st_off(W.vrad, out_g[c], o_vr[c]);
+                        st_off(W.vazi, out_g[c], o_va[c]);
+                        st_off(W.sigma, out_g[c], o_s[c]);
                         if (ADI)
-                            W.energy[out_g[c]] = o_e[c];
+                            st_off(W.energy, out_g[c], o_e[c]);
                     }
             }
             if (i == nr - 1) { // v_r row Nr is neither transported nor shifted: copied column by column
 #pragma unroll
                 for (int c = 0; c < C; ++c)
                     if (valid[c]) {
-                        double v = P.vrad[nr * nphi + jin[c]];
+                        const unsigned gt = ((unsigned)nr * (unsigned)nphi + (unsigned)jin[c]) * 8u;
+                        double v = ld_off(P.vrad, gt);
                         if (DAMP) {
                             const DampRow dn = crow_load(W.damp_tab, nr);
-                            v = damp_apply(v, dn.tvr, si.ev_top, W.vrad0, nr * nphi + jin[c], 0.0);
+                            v = damp_apply(v, dn.tvr, si.ev_top, W.vrad0, gt, 0.0);
                         }
-                        W.vrad[nr * nphi + jin[c]] = v;
+                        st_off(W.vrad, gt, v);
                     }
             }
         }
