@@ -206,3 +206,12 @@ __device__ __forceinline__ bool shift_jump_raised(const int *flag)
     const int __attribute__((address_space(4))) *f = (const int __attribute__((address_space(4))) *)flag;
     return f[0] == f[2];
 }
+
+// Addresses as 32-bit BYTE offsets from a grid's base: the launchers only take the marching kernels for grids below
+// 4 GiB each (2^29 cells), so base (scalar registers) + zext(offset) is the saddr form of global_load / global_store -- one VGPR
+// per address instead of two, and no 64-bit address arithmetic in the vector unit (nine v_lshl_add_u64 per ring before).
+__device__ __forceinline__ double ld_off(const double *base, unsigned off) { return *(const double *)((const char *)base + off); }
+__device__ __forceinline__ void st_off(double *base, unsigned off, double v) { *(double *)((char *)base + off) = v; }
+__device__ __forceinline__ D2 ld2_off(const double *base, unsigned off) { return LD2((const double *)((const char *)base + off)); }
+__device__ __forceinline__ void st2_off(double *base, unsigned off, D2 v) { ST2((double *)((char *)base + off), v); }
+

@@ -233,6 +233,8 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
         *bc_folded = false;
     if (P.nphi < 128)
         return 0;
+    if ((long long)(P.nr + 1) * P.nphi >= (1ll << 29))
+        return 0; // the kernels address cells by 32-bit byte offsets (ld_off): grids below 4 GiB
     int bc_fold = 0;
     {
         // the boundary conditions read rows 1, 2 and nr-2 .. nr of the kick's result: the wavefront that applies them

@@ -32,6 +32,21 @@
 #ifndef FAST_RSQRT_SRC
 #define FAST_RSQRT_SRC fast_rsqrt
 #endif
+// byte offset of cell (ring r_, this lane's column) in a grid: 32-bit (see ld_off)
+#define MOFF(r_) (((unsigned)(r_) * (unsigned)nphi + (unsigned)j) * 8u)
+#ifndef ADI_OFF32
+#define ADI_OFF32 1 /* loads only: with the stores in this form too the 128-register kernel spills 12 bytes and loses 14 us */
+#endif
+#if ADI_OFF32 & 1
+#define ADI_LD(g_, r_) ld_off(g_, MOFF(r_))
+#else
+#define ADI_LD(g_, r_) (g_)[IDX(r_, j)]
+#endif
+#if ADI_OFF32 & 2
+#define ADI_ST(g_, r_, v_) st_off(g_, MOFF(r_), v_)
+#else
+#define ADI_ST(g_, r_, v_) (g_)[IDX(r_, j)] = (v_)
+#endif
 #define MARCH_VALID 59
 #define MARCH_LO 3
 
@@ -118,17 +133,17 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
     // ring k0-3 is the "previous" ring of the first iteration
     {
         const int r = crow(k0 - 3);
-        S_m = P.sigma[IDX(r, j)];
-        F_m = fgrid[IDX(r, j)];
-        va0_m = P.vazi[IDX(r, j)];
+        S_m = ld_off(P.sigma, MOFF(r));
+        F_m = ld_off(fgrid, MOFF(r));
+        va0_m = ld_off(P.vazi, MOFF(r));
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
     }
     // software prefetch of the next input ring
     int rn = k0 - 2;
-    double pS = P.sigma[IDX(crow(rn), j)], pF = fgrid[IDX(crow(rn), j)];
-    double pG = ACC ? P.accel_az[IDX(crow(rn), j)] : 0.0;
-    double pVa = P.vazi[IDX(crow(rn), j)], pVr = P.vrad[IDX(vrow(rn), j)];
+    double pS = ld_off(P.sigma, MOFF(crow(rn))), pF = ld_off(fgrid, MOFF(crow(rn)));
+    double pG = ACC ? ld_off(P.accel_az, MOFF(crow(rn))) : 0.0;
+    double pVa = ld_off(P.vazi, MOFF(crow(rn))), pVr = ld_off(P.vrad, MOFF(vrow(rn)));
 
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
         const SrcRow R = crow_load(P.src_tab, m + 2); // every per-ring factor of this iteration, one batch
@@ -143,12 +158,12 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
         const double vr0_m = pVr;
         {
             const int r = m + 1;
-            pS = P.sigma[IDX(crow(r), j)];
-            pF = fgrid[IDX(crow(r), j)];
+            pS = ld_off(P.sigma, MOFF(crow(r)));
+            pF = ld_off(fgrid, MOFF(crow(r)));
             if (ACC)
-                pG = P.accel_az[IDX(crow(r), j)];
-            pVa = P.vazi[IDX(crow(r), j)];
-            pVr = P.vrad[IDX(vrow(r), j)];
+                pG = ld_off(P.accel_az, MOFF(crow(r)));
+            pVa = ld_off(P.vazi, MOFF(crow(r)));
+            pVr = ld_off(P.vrad, MOFF(vrow(r)));
         }
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
@@ -269,8 +284,8 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                     const ViscFactors f = visc_factors_row(P, k, nsrp_2, nsrp_1, nsrp_jn, R.nu_d * S_2, R.nu_d * Sp_2,
                                                            nu_d_prev * S_3, S_2, Sp_2, S_3);
                     if (store_lane) {
-                        P.cfac_phi[IDX(k, j)] = f.cphi;
-                        P.cfac_r[IDX(k, j)] = f.cr;
+                        st_off(P.cfac_phi, MOFF(k), f.cphi);
+                        st_off(P.cfac_r, MOFF(k), f.cr);
                     }
                     if (P.stabilize == 1) {
                         corr_phi = visc_corr_march(dt, f.cphi);
@@ -292,9 +307,9 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
                     vr3 = vr2_2 + (STAB ? dVr * corr_r : dVr);
                 }
                 if (store_lane) {
-                    P.vrad_b[IDX(k, j)] = vr3;
+                    st_off(P.vrad_b, MOFF(k), vr3);
                     if (k < nr)
-                        P.vazi_b[IDX(k, j)] = va3;
+                        st_off(P.vazi_b, MOFF(k), va3);
                 }
                 if (ring_sums && k < nr) { // this segment's share of sum_j v_phi(k, j) for the transport's <v_phi>
                     const double part = wave_sum(store_lane ? va3 : 0.0);
@@ -425,18 +440,18 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
     // ring k0-3 is the "previous" ring of the first iteration
     {
         const int r = crow(k0 - 3);
-        S_m = P.sigma[IDX(r, j)];
-        va0_m = P.vazi[IDX(r, j)];
-        e0_m = P.energy[IDX(r, j)];
-        F_m = POT ? potential_of(r, S_m, e0_m) : fgrid[IDX(r, j)];
+        S_m = ADI_LD(P.sigma, r);
+        va0_m = ADI_LD(P.vazi, r);
+        e0_m = ADI_LD(P.energy, r);
+        F_m = POT ? potential_of(r, S_m, e0_m) : ADI_LD(fgrid, r);
         Sp_m = PREV(S_m);
         va0n_m = NEXT(va0_m);
     }
     // software prefetch of the next input ring
     int rn = k0 - 2;
-    double pS = P.sigma[IDX(crow(rn), j)], pF = POT ? 0.0 : fgrid[IDX(crow(rn), j)], pE = P.energy[IDX(crow(rn), j)];
-    double pG = ACC ? P.accel_az[IDX(crow(rn), j)] : 0.0;
-    double pVa = P.vazi[IDX(crow(rn), j)], pVr = P.vrad[IDX(vrow(rn), j)];
+    double pS = ADI_LD(P.sigma, crow(rn)), pF = POT ? 0.0 : ADI_LD(fgrid, crow(rn)), pE = ADI_LD(P.energy, crow(rn));
+    double pG = ACC ? ADI_LD(P.accel_az, crow(rn)) : 0.0;
+    double pVa = ADI_LD(P.vazi, crow(rn)), pVr = ADI_LD(P.vrad, vrow(rn));
 
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
         const SrcRow R = crow_load(P.src_tab, m + 2); // every per-ring factor of this iteration, one batch
@@ -460,14 +475,14 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
         const double vr0_m = pVr;
         {
             const int r = m + 1;
-            pS = P.sigma[IDX(crow(r), j)];
+            pS = ADI_LD(P.sigma, crow(r));
             if (!POT)
-                pF = fgrid[IDX(crow(r), j)];
+                pF = ADI_LD(fgrid, crow(r));
             if (ACC)
-                pG = P.accel_az[IDX(crow(r), j)];
-            pE = P.energy[IDX(crow(r), j)];
-            pVa = P.vazi[IDX(crow(r), j)];
-            pVr = P.vrad[IDX(vrow(r), j)];
+                pG = ADI_LD(P.accel_az, crow(r));
+            pE = ADI_LD(P.energy, crow(r));
+            pVa = ADI_LD(P.vazi, crow(r));
+            pVr = ADI_LD(P.vrad, vrow(r));
         }
         if (POT)
             F_m = potential_of(crow(m), S_m, e0_m);
@@ -614,8 +629,8 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                     const ViscFactors f = visc_factors_row(P, k, nsrp_2, nsrp_1, nsrp_jn, nu_2 * S_2, nup_2 * Sp_2,
                                                            nu_3 * S_3, S_2, Sp_2, S_3);
                     if (store_lane) {
-                        P.cfac_phi[IDX(k, j)] = f.cphi;
-                        P.cfac_r[IDX(k, j)] = f.cr;
+                        ADI_ST(P.cfac_phi, k, f.cphi);
+                        ADI_ST(P.cfac_r, k, f.cr);
                     }
                     if (P.stabilize == 1) {
                         corr_phi = visc_corr_march(dt, f.cphi);
@@ -667,18 +682,18 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                     e = clamp_energy_fast(P, e, S_2); // SetTemperatureFloorCeilValues
                 }
                 if (store_lane) {
-                    P.vrad_b[IDX(k, j)] = vr3;
+                    ADI_ST(P.vrad_b, k, vr3);
                     if (k < nr) {
-                        P.vazi_b[IDX(k, j)] = va3;
-                        P.energy_b[IDX(k, j)] = e;
-                        P.qplus[IDX(k, j)] = qplus;
-                        P.qminus[IDX(k, j)] = qminus;
-                        P.qdiff[IDX(k, j)] = qplus - qminus; // what the CFL condition needs of the two (cfl.cpp:303-316)
+                        ADI_ST(P.vazi_b, k, va3);
+                        ADI_ST(P.energy_b, k, e);
+                        ADI_ST(P.qplus, k, qplus);
+                        ADI_ST(P.qminus, k, qminus);
+                        ADI_ST(P.qdiff, k, qplus - qminus); // what the CFL condition needs of the two (cfl.cpp:303-316)
                         // step_LeapFrog evaluates the mid-step potential with the scale height this kick's
                         // recalculate_viscosity left behind (simulation.cpp:340-378), not with that of the
                         // transported state: keep the grid for it
                         if (P.leapfrog)
-                            P.scale_height[IDX(k, j)] = H_2;
+                            ADI_ST(P.scale_height, k, H_2);
                     }
                 }
                 if (ring_sums && k < nr) { // this segment's share of sum_j v_phi(k, j) for the transport's <v_phi>

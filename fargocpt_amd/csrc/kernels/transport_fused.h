@@ -39,14 +39,6 @@ template <int C> struct TfHalo {
 // reference value and its use sit in one basic block: a load whose use is behind another branch leaves the compiler's
 // s_waitcnt pass with a "maybe pending" register at every later store of the loop, and the pinned prefetch (bottom
 // of the loop) would be waited for on the spot again.
-// Addresses as 32-bit BYTE offsets from a grid's base: the launcher only takes this kernel for grids below 4 GiB each
-// (2^29 cells), so base (scalar registers) + zext(offset) is the saddr form of global_load / global_store -- one VGPR
-// per address instead of two, and no 64-bit address arithmetic in the vector unit (nine v_lshl_add_u64 per ring before).
-__device__ __forceinline__ double ld_off(const double *base, unsigned off) { return *(const double *)((const char *)base + off); }
-__device__ __forceinline__ void st_off(double *base, unsigned off, double v) { *(double *)((char *)base + off) = v; }
-__device__ __forceinline__ D2 ld2_off(const double *base, unsigned off) { return LD2((const double *)((const char *)base + off)); }
-__device__ __forceinline__ void st2_off(double *base, unsigned off, D2 v) { ST2((double *)((char *)base + off), v); }
-
 __device__ __forceinline__ double damp_apply(double X, int type, double ef, const double *ref, unsigned cell_off, double zero_target)
 {
     if (type == 1) {
