@@ -256,6 +256,20 @@ class Context:
         self._call("get_option", C.c_char_p(name.encode()), C.byref(v))
         return v.value
 
+    def set_transport_chunks(self, lengths):
+        """Explicit chunk lengths of the fused transport kernel in dispatch order (empty: the built-in grading)."""
+        a = np.ascontiguousarray(lengths, dtype=np.int32)
+        self._call("set_transport_chunks", a.ctypes.data_as(C.POINTER(_i32)), _i32(a.size))
+
+    def transport_chunks(self) -> np.ndarray:
+        """(first ring, one past the last) of every chunk of the fused transport kernel, dispatch order; empty: equal chunks."""
+        n = _i32()
+        self._call("transport_chunks", None, _i32(0), C.byref(n))
+        out = np.zeros((n.value, 2), dtype=np.int32)
+        if n.value:
+            self._call("transport_chunks", out.ctypes.data_as(C.POINTER(_i32)), _i32(n.value), C.byref(n))
+        return out
+
     # radial slabs over RCCL inside the library
     def comm_init(self, unique_id: bytes):
         assert len(unique_id) == COMM_ID_BYTES

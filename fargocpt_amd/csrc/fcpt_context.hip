@@ -59,6 +59,8 @@ int *option_slot(Options &o, const char *name)
 void options_from_environment(Options &o)
 {
     o.transport_fused = o.transport_rows = o.source_rows = o.theta_rows = -1;
+    o.transport_graded = 1;
+    o.transport_big = o.transport_ladder = -1;
     o.transport_fallback = o.transport_split = o.fused_source = o.march_source = o.march_source_adi = 1;
     o.theta_march = o.theta_fused = o.cfl_rings = o.cfl_split = o.source_ring_parts = o.fused_damping = 1;
     o.inline_potential = 1;
@@ -168,6 +170,22 @@ void apply_options(fcpt_ctx *c, bool at_create = true)
     c->cfl_interior = false;
     c->potential_valid = false;
     c->pressure_valid = false;
+    // the chunk table of the fused transport (the caller has synchronised the stream, or nothing has run yet)
+    c->P.tf_sched = nullptr;
+    c->P.tf_sched_n = 0;
+    if (c->tf_sched_dev) {
+        std::vector<int> slow(c->P.nr, 0);
+        if (c->P.damp_in_step)
+            slow = c->ring_ref_damped;
+        const std::vector<int> sched = transport_schedule(c->P, slow, &c->tf_lengths);
+        c->tf_sched_host.clear();
+        if (!sched.empty() && sched.size() <= (size_t)2 * (c->P.nr + 8) &&
+            hipMemcpy(c->tf_sched_dev, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
+            c->P.tf_sched = c->tf_sched_dev;
+            c->P.tf_sched_n = (int)(sched.size() / 2);
+            c->tf_sched_host = sched;
+        }
+    }
     if (!at_create && c->P.adiabatic && !c->P.lazy_derived) {
         launch_derived(c->P, c->stream); // the kernels that read c_s, H, nu, T from the grids expect them current
         c->pressure_valid = true;
@@ -651,6 +669,28 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         for (int i = 0; i <= nr; ++i)
             dr[i] = DampRow{fs[i], ts[i], fv[i], tv[i], ty[0][i], ty[1][i], ty[2][i], ty[3][i], {0.0, 0.0}};
         if (!rc) rc = dev_upload_raw(c, &P.damp_tab, dr);
+        c->ring_ref_damped.assign(nr, 0);
+        for (int i = 0; i < nr; ++i)
+            c->ring_ref_damped[i] = (ty[0][i] == 1 || ty[1][i] == 1 || ty[2][i] == 1 || ty[3][i] == 1) ? 1 : 0;
+        if (!rc) rc = dev_alloc(c, &c->tf_sched_dev, (size_t)2 * (nr + 8));
+        if (const char *q = getenv("FCPT_TF_SCHEDULE")) { // tuning runs: "28x56,12x24,6" = 56 chunks of 28 rings, 24 of 12, the rest of 6
+            while (*q) {
+                char *e = nullptr;
+                const long a = strtol(q, &e, 10);
+                if (e == q)
+                    break;
+                long n = 1;
+                q = e;
+                if (*q == 'x' || *q == 'X') {
+                    n = strtol(q + 1, &e, 10);
+                    q = e;
+                }
+                for (long k = 0; k < n && (long)c->tf_lengths.size() < 4l * nr; ++k)
+                    c->tf_lengths.push_back((int)(a < 1 ? 1 : a));
+                while (*q == ',' || *q == ' ')
+                    ++q;
+            }
+        }
         if (rc) {
             fcpt_destroy(c);
             return rc;
@@ -733,6 +773,40 @@ int fcpt_get_option(const fcpt_ctx *c, const char *name, int32_t *value)
         return FCPT_EINVAL;
     }
     *value = *slot;
+    return FCPT_OK;
+}
+
+int fcpt_set_transport_chunks(fcpt_ctx *c, const int32_t *lengths, int32_t n)
+{
+    if (!c || n < 0 || (n > 0 && !lengths))
+        return FCPT_EINVAL;
+    if (c->stepped) {
+        set_error("fcpt_set_transport_chunks between fcpt_step and fcpt_post");
+        return FCPT_EINVAL;
+    }
+    for (int k = 0; k < n; ++k)
+        if (lengths[k] < 1) {
+            set_error("fcpt_set_transport_chunks: chunk %d has %d rings", k, (int)lengths[k]);
+            return FCPT_EINVAL;
+        }
+    join_side(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->tf_lengths.assign(lengths, lengths + n);
+    apply_options(c, false);
+    HIPCHK(hipGetLastError());
+    return FCPT_OK;
+}
+
+int fcpt_transport_chunks(const fcpt_ctx *c, int32_t *first_last, int32_t capacity, int32_t *n_chunks)
+{
+    if (!c || !n_chunks || capacity < 0 || (capacity > 0 && !first_last))
+        return FCPT_EINVAL;
+    const int n = (int)(c->tf_sched_host.size() / 2);
+    *n_chunks = n;
+    for (int k = 0; k < n && k < capacity; ++k) {
+        first_last[2 * k] = c->tf_sched_host[2 * k];
+        first_last[2 * k + 1] = c->tf_sched_host[2 * k + 1];
+    }
     return FCPT_OK;
 }
 

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "fcpt_comm.h"
@@ -62,6 +63,10 @@ struct fcpt_ctx {
     double *thermal_grid = nullptr; // storage of Dev::cfl_thermal (the view's pointer is null when the option is off)
     bool thermal_valid = false;     // ... and it describes the current state (set by a marching-transport step)
     bool qdiff_valid = false;       // Dev::qdiff holds Q+ - Q- of the grids (written by the last kick's march)
+    std::vector<int> ring_ref_damped; // per ring: 1 if the folded damping loads reference values there (costlier rings of the transport)
+    int *tf_sched_dev = nullptr;      // storage of Dev::tf_sched (2 (nr + 8) ints)
+    std::vector<int> tf_lengths;      // explicit chunk lengths in dispatch order (fcpt_set_transport_chunks; FCPT_TF_SCHEDULE at fcpt_create); empty: built-in
+    std::vector<int> tf_sched_host;   // what Dev::tf_sched holds
     bool damp_foldable = false; // ... and its damping can be folded into the transport (no "mean" target, Euler)
     // fcpt_step_device_begin: the interior chunks of the transport run on `side` while the caller's stream
     // marches the chunks with the neighbours' ghost rings, packs and sends them

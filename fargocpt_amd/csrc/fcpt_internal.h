@@ -134,7 +134,10 @@ struct alignas(64) DampRow { // ring i (nr + 1 rows: v_r has row nr)
 // environment.  A value of -1 means "not set: the launcher's built-in choice".
 struct Options {
     int transport_fused;    // 0: off, 1 | 2: k_transport_fused with 1 | 2 cells per lane (rings of >= 256 cells)
-    int transport_rows;     // rings per marching chunk of k_transport_fused
+    int transport_rows;     // rings per marching chunk of k_transport_fused (> 0: equal chunks of that many rings)
+    int transport_graded;   // 1: chunks of graded length, long ones first (transport_schedule()); 0: equal chunks
+    int transport_big;      // graded: rings per chunk of the first round (-1: from the grid and the wavefront slots)
+    int transport_ladder;   // graded: per cent of the previous length each further round of chunks gets (-1: built-in)
     int source_rows;        // ... of k_source_march(_adi)
     int theta_rows;         // ... of k_transport_theta_march
     int transport_fallback; // 1: the two-kernel transport is queued behind every k_transport_fused
@@ -158,7 +161,7 @@ struct Options {
     int profile_stride;     // fcpt_profile_start: every n-th launch of the selected kernels is timed (an event pair costs ~3 us of stream time)
 };
 #define FCPT_OPTION_NAMES                                                                                        \
-    X(transport_fused) X(transport_rows) X(source_rows) X(theta_rows) X(transport_fallback) X(transport_split)    \
+    X(transport_fused) X(transport_rows) X(transport_graded) X(transport_big) X(transport_ladder) X(source_rows) X(theta_rows) X(transport_fallback) X(transport_split)    \
     X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_split)   \
     X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(bc_in_cfl) X(comm_overlap) X(comm_loopback) X(graph_steps) X(profile_stride)
 
@@ -211,6 +214,8 @@ struct Dev {
     const ThetaRow *theta_tab;
     ShiftRow *shift_tab;
     const DampRow *damp_tab;
+    const int *tf_sched;    // chunks of k_transport_fused in dispatch order: (first ring, one past the last) pairs
+    int tf_sched_n;         // ... how many (0: equal chunks of transport_rows() rings)
     int *shift_jump;        // set by k_transport_fused when |Nshift[i]-Nshift[i-1]| > 1 somewhere: the unfused kernels take over
     // wave damping folded into the end of the transport step: per-ring factor f = ((r-r_lim)/(r_edge-r_lim))^2
     // and time scale tau for scalar (dfac_s/dtau_s, nr) and vector (dfac_v/dtau_v, nr+1) grids, and the

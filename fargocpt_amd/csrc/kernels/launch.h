@@ -193,6 +193,88 @@ static int source_rows(const Dev &P)
     }
     return r;
 }
+// Chunks of graded length for k_transport_fused, in dispatch order: (first ring, one past the last) pairs.
+//
+// Why: the wavefront trace of the kernel (profiles/tools/wave_trace_transport.py, profiles/r03_tf_wave_trace.txt) shows
+// equal chunks leaving a long tail.  At 2048 x 4096 the 8 034 wavefronts of 103 twenty-ring chunks take two rounds of
+// the 4 096 slots; a SIMD issues for its OLDEST wavefront first, so the four wavefronts of a SIMD finish 58 ... 95 us
+// after a common start, the second round starts staggered over 40 us and ends staggered over 58 us, during which the
+// GPU holds 1 900 wavefronts on average: 188 us for 150 us of full-occupancy work.  Long chunks first and ever shorter
+// ones behind them (guided self-scheduling) let the slots run dry together: the last wavefronts a slot receives are
+// short, and their pre-roll (4 cheap + 1 full iteration per chunk) is paid on a small share of the rings only.
+//
+// Three lengths (see the body for the numbers).  Chunks are taken from both ends of the
+// slab alternately (the damping zones -- costlier rings, `slow` = 1 -- sit at the ends and start first, and they
+// count 1.4 rings each).  Returns an empty vector where equal chunks stay: tuning runs (transport_rows > 0,
+// transport_graded = 0) and grids whose wavefronts fit the slots once (the shortest chunks win there: transport_rows()).
+static int transport_rows(const Dev &P);
+std::vector<int> transport_schedule(const Dev &P, const std::vector<int> &slow, const std::vector<int> *lengths)
+{
+    std::vector<int> out;
+    if (P.nphi < 256 || P.opt.transport_rows > 0 || P.opt.transport_graded == 0)
+        return out;
+    if (P.opt.transport_fused == 0 || P.opt.transport_fused == 2)
+        return out;
+    const int tstride = 64 - (TfHalo<1>::lo + TfHalo<1>::hi);
+    const long tiles = (P.nphi + tstride - 1) / tstride;
+    const long slots = (long)device_cus() * 4 * 4; // 4 wavefronts per SIMD (128 VGPRs)
+    const double conc = (double)slots / (double)tiles; // chunks resident at once
+    const bool explicit_spec = lengths && !lengths->empty(); // fcpt_set_transport_chunks / FCPT_TF_SCHEDULE: tuning runs and tests
+    if (!explicit_spec) {
+        const int rows_u = transport_rows(P);
+        if ((long)((P.nr + rows_u - 1) / rows_u) * tiles <= slots || conc < 16.0)
+            return out; // equal chunks need one round only / rings so long that a few chunks fill an XCD
+    }
+    const int COST = 10, COST_SLOW = 14; // tenths of a ring
+    long total = 0;
+    for (int i = 0; i < P.nr; ++i)
+        total += (i < (int)slow.size() && slow[i]) ? COST_SLOW : COST;
+    // lengths in dispatch order, in rings of cost
+    std::vector<int> len;
+    if (explicit_spec) {
+        len = *lengths;
+    } else {
+        // level 0: the same number of chunks for every XCD (they are dealt round-robin), enough of them to fill the
+        // XCD's slots once; 74 % of the cost there, then three chunks per XCD of 0.43 of that length, the rest at 0.21
+        // (measured at 2048 x 4096, 78 tiles, 512 slots per XCD: 28 x 56, 12 x 24, 6 ...: profiles/r03_tf_schedule_sweep.txt)
+        const long slots_xcd = slots / 8;
+        const int k0 = (int)((slots_xcd + tiles - 1) / tiles);
+        const int n0 = 8 * k0;
+        int big = P.opt.transport_big > 0 ? P.opt.transport_big : (int)(0.74 * (double)total / COST / n0 + 0.5);
+        big = big < 4 ? 4 : big;
+        const double ladder = (P.opt.transport_ladder > 0 && P.opt.transport_ladder <= 100 ? P.opt.transport_ladder : 43) * 0.01;
+        const int n1 = 8 * ((int)(0.43 * k0 + 0.5) < 1 ? 1 : (int)(0.43 * k0 + 0.5));
+        const int l1 = (int)(big * ladder + 0.5) < 4 ? 4 : (int)(big * ladder + 0.5);
+        const int l2 = (int)(big * ladder * 0.5 + 0.5) < 4 ? 4 : (int)(big * ladder * 0.5 + 0.5);
+        for (int k = 0; k < n0; ++k)
+            len.push_back(big);
+        for (int k = 0; k < n1; ++k)
+            len.push_back(l1);
+        len.push_back(l2); // ... repeated to the end
+    }
+    int lo = 0, hi = P.nr;
+    for (size_t k = 0; lo < hi; ++k) {
+        const int lk = len[k < len.size() ? k : len.size() - 1];
+        const long target = (long)(lk < 1 ? 1 : lk) * COST;
+        long cost = 0;
+        if ((k & 1) == 0) {
+            const int r0 = lo;
+            while (lo < hi && cost < target)
+                cost += (lo < (int)slow.size() && slow[lo]) ? COST_SLOW : COST, ++lo;
+            if (hi - lo < 3) // no crumbs
+                lo = hi;
+            out.push_back(r0), out.push_back(lo);
+        } else {
+            const int r1 = hi;
+            while (lo < hi && cost < target)
+                cost += (hi - 1 < (int)slow.size() && slow[hi - 1]) ? COST_SLOW : COST, --hi;
+            if (hi - lo < 3)
+                hi = lo;
+            out.push_back(hi), out.push_back(r1);
+        }
+    }
+    return out;
+}
 // The transport deals whole chunks to the 8 XCDs (k_transport_fused), so the rounds are counted per XCD; and its
 // chunks are not equal: the rings of the damping zones (folded into the kernel) cost ~1.5x and are started first, which
 // adds half a round to the last one.  cost = (rows + 5) x (rounds - 1 + slow).  Measured: 2048 x 4096 (78 tiles): 20
@@ -526,13 +608,15 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         // spreading ring), and the reference shifts by any amount.  FCPT_TRANSPORT_FALLBACK=0 drops the launches
         // for flows known to be benign; a violation is then reported as FCPT_ESHEAR.
         const int fallback = P.opt.transport_fallback != 0;
-        TfChunks ch = {chunks, chunks, 0, 1};
+        TfChunks ch = {chunks, chunks, 0, 1, nullptr};
+        if (part == TRANSPORT_ALL && P.tf_sched_n > 0 && P.opt.transport_rows <= 0 && CF == 1)
+            ch = TfChunks{P.tf_sched_n, P.tf_sched_n, 0, 1, P.tf_sched};
         const int c_lo = (P.nr - 2 * FCPT_OVERLAP) / rows;    // first chunk of the outer tail (holds row nr - 14)
         const int lead = (2 * FCPT_OVERLAP + rows - 1) / rows; // chunks that hold rows [0, 14)
         if (part == TRANSPORT_EDGES)
-            ch = TfChunks{lead + (chunks - c_lo), lead, c_lo - lead, 1};
+            ch = TfChunks{lead + (chunks - c_lo), lead, c_lo - lead, 1, nullptr};
         else if (part == TRANSPORT_INTERIOR)
-            ch = TfChunks{c_lo - lead, 0, lead, 0};
+            ch = TfChunks{c_lo - lead, 0, lead, 0, nullptr};
         res.split = part != TRANSPORT_ALL;
         // (8 XCDs x the wavefronts of ceil(count / 8) chunks, four to a workgroup: see the chunk mapping in the kernel)
         const dim3 grid(ch.count >= TF_XCD_CHUNKS ? 8 * ((((ch.count + 7) / 8) * tiles + 3) / 4) : (ch.count * tiles + 3) / 4), block(256);

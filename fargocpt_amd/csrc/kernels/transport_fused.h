@@ -27,8 +27,11 @@
 // `skip` chunks further up.  All chunks at once: {n, n, 0, 1}.  Slabs with neighbours march the chunks that hold
 // the rings the neighbours are waiting for first (fcpt_step_device_begin): {1 + tail, 1, gap, 1} then {gap, 0, 1, 0}.
 #define TF_XCD_CHUNKS 16 /* launches of at least this many chunks deal whole chunks to the XCDs */
+// sched != null: chunk c of the launch is rings [sched[2c], sched[2c+1]) -- graded lengths, long chunks first
+// (transport_schedule() in launch.h); the table is in dispatch order, so lead / skip do not apply.
 struct TfChunks {
     int count, lead, skip, advance_clock;
+    const int *sched;
 };
 template <int C> struct TfHalo {
     static constexpr int lo = C == 2 ? 6 : 5; // even for C = 2: a lane's two cells are final together
@@ -108,12 +111,23 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     int chunk = chunk_l < ch.lead ? chunk_l : chunk_l + ch.skip;
     if (ch.lead == ch.count && ch.skip == 0) // all chunks in one launch: 0, n-1, 1, n-2, ...
         chunk = (chunk_l & 1) ? ch.count - 1 - (chunk_l >> 1) : (chunk_l >> 1);
-    const int r0 = chunk * rows;
     const int nr = P.nr, nphi = P.nphi;
+    int r0 = chunk * rows, r1 = r0 + rows < nr ? r0 + rows : nr;
+    if (ch.sched) {
+        const int __attribute__((address_space(4))) *tab = (const int __attribute__((address_space(4))) *)ch.sched;
+        chunk = chunk_l;
+        r0 = tab[2 * chunk_l], r1 = tab[2 * chunk_l + 1];
+    }
     if (r0 >= nr)
         return;
-    const int r1 = r0 + rows < nr ? r0 + rows : nr;
     const int tile = wave - chunk_l * tiles;
+#ifdef TF_TRACE /* profiles/tools/wave_trace_transport.py: start and end of every wavefront, 10 ns ticks, in the (isothermal: unused) temperature grid */
+    if (lane == 0) {
+        W.temperature[4 * (chunk * tiles + tile)] = (double)wall_clock64();
+        W.temperature[4 * (chunk * tiles + tile) + 2] = (double)r0;
+        W.temperature[4 * (chunk * tiles + tile) + 3] = (double)r1;
+    }
+#endif
     const int stride = 64 * C - (LO + HI);
     const int a = tile * stride - LO; // first pre-shift column of the segment
     const double dt = P.clk->dt;
@@ -461,6 +475,10 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
             }
         }
     }
+#ifdef TF_TRACE
+    if (lane == 0)
+        W.temperature[4 * (chunk * tiles + tile) + 1] = (double)wall_clock64();
+#endif
 }
 
 // The kernels proper.  One cell per lane: the register allocator is told to aim for 4 wavefronts per SIMD (<= 128

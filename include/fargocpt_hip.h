@@ -310,7 +310,7 @@ int fcpt_synchronize(fcpt_ctx *ctx);
 /* Kernel-selection switches of one context, by name (lower case, e.g. "transport_fallback"): which of the
  * parity-tested kernel variants the step uses, marching-chunk lengths, overlap of the ghost exchange.  The
  * environment variables FCPT_<NAME> only provide the defaults read once in fcpt_create; no launch reads the
- * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows,
+ * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows, transport_graded, transport_big, transport_ladder,
  * source_rows, theta_rows, transport_fallback, transport_split, fused_source, march_source, march_source_adi,
  * theta_march, theta_fused, cfl_rings, cfl_split, source_ring_parts, fused_damping, inline_potential, cfl_thermal, bc_fold, bc_in_cfl, comm_overlap,
  * comm_loopback, graph_steps, profile_stride (fcpt_profile_start times every n-th launch of the selected kernels).
@@ -321,6 +321,17 @@ int fcpt_synchronize(fcpt_ctx *ctx);
  * FCPT_EINVAL for an unknown name.  (The reference has no counterpart: its variants are compile-time.) */
 int fcpt_set_option(fcpt_ctx *ctx, const char *name, int32_t value);
 int fcpt_get_option(const fcpt_ctx *ctx, const char *name, int32_t *value);
+
+/* The chunks of rings into which the fused Transport() kernel (src/TransportEuler.cpp:112-136 as one marching pass)
+ * divides the slab, in the order they are dispatched: the library grades their lengths (long chunks first, options
+ * transport_graded / transport_big / transport_ladder) so that the GPU's wavefront slots run dry together.  The
+ * chunking never changes a result -- every ring is computed by exactly one chunk from the same operands.
+ * fcpt_transport_chunks reports the table in use as (first ring, one past the last ring) pairs (n_chunks = 0: equal
+ * chunks of transport_rows rings); fcpt_set_transport_chunks replaces the lengths by an explicit list, the last entry
+ * repeating to the end of the slab (n = 0: back to the built-in grading) -- a tuning and test hook, like the options.
+ * (No counterpart in the reference: its loops are not chunked.) */
+int fcpt_set_transport_chunks(fcpt_ctx *ctx, const int32_t *lengths, int32_t n);
+int fcpt_transport_chunks(const fcpt_ctx *ctx, int32_t *first_last, int32_t capacity, int32_t *n_chunks);
 
 int fcpt_get_split(const fcpt_ctx *ctx, fcpt_split *out);
 int fcpt_get_clock(const fcpt_ctx *ctx, fcpt_clock *out);

@@ -187,3 +187,42 @@ def test_bench_loop_is_reproducible_bit_for_bit(product, adiabatic):
     for k in ("sigma", "vrad", "vazi") + (("energy",) if adiabatic else ()):
         assert np.array_equal(a[k], b[k]), k
     assert all(np.isfinite(v).all() for v in a.values())
+
+
+@pytest.mark.parametrize("adiabatic", [False, True])
+def test_graded_transport_chunks_at_full_size(product, adiabatic):
+    """At the bench size the fused transport needs two rounds of the GPU's wavefront slots, and the library grades its
+    chunk lengths (transport_schedule in kernels/launch.h): the table must hold every ring exactly once, start with
+    the same number of long chunks for each of the 8 XCDs, end with short ones -- and give the bits of equal chunks."""
+    d = setups.planet_disk(product, NR, NPHI, adiabatic=adiabatic)
+    d0 = d.copy()
+    radii = product.radii(d0)
+    fields = perturb(product.initial_fields(d0, radii), d0, 1e-3)
+    bodies = setups.jupiter_bodies(d0)
+    out = []
+    for graded in (1, 0):
+        ctx = driver.make_context(product, d0, fields=fields, radii=radii, bodies=bodies)
+        ctx.set_option("transport_graded", graded)
+        tab = ctx.transport_chunks()
+        if graded:
+            assert len(tab) > 16
+            order = np.argsort(tab[:, 0])
+            assert tab[order[0], 0] == 0 and tab[order[-1], 1] == NR
+            assert np.array_equal(tab[order[1:], 0], tab[order[:-1], 1])
+            n = tab[:, 1] - tab[:, 0]
+            assert (n >= 1).all() and n[:8].min() > 2 * n[-8:].max()
+            damp = ctx.get_option("fused_damping")
+            assert damp == 1
+            big = n[16]                                 # (the first chunks sit in the damping zones: fewer, costlier rings)
+            n_long = int(np.argmax(n < 0.6 * big))      # chunks before the first markedly shorter one
+            assert n_long >= 8 and n_long % 8 == 0, (n_long, n[:80])
+        else:
+            assert len(tab) == 0
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        assert ctx.run_steps(12) == 12
+        out.append((ctx.state(), ctx.clock.time))
+        ctx.close()
+    assert out[0][1] == out[1][1]
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k

@@ -717,6 +717,54 @@ def test_graph_replay_is_bit_identical(product, case):
         assert np.array_equal(out[0][0][k], out[1][0][k]), k
 
 
+@pytest.mark.parametrize("case", ["iso_96x512", "ideal_61x320_sn", "iso_reference_bc_40x263"])
+def test_transport_chunk_lengths_never_change_a_result(product, case):
+    """The fused transport kernel divides the slab into chunks of rings, each marched by its own wavefronts; the
+    library grades their lengths (long ones first) on grids that need more than one round of the GPU's wavefront
+    slots.  Every ring is computed by exactly one chunk from the same operands, so ANY list of lengths gives the
+    bits of the equal chunks -- here ragged lists (single rings, a chunk longer than the slab's remainder, the last
+    entry repeating), damping zones at both ends, against transport_graded = 0."""
+    from fargocpt_amd import driver
+    if case == "iso_96x512":
+        d, lengths = setups.planet_disk(product, 96, 512), [7, 7, 7, 1, 5, 13, 3]
+    elif case == "ideal_61x320_sn":
+        d, lengths = setups.planet_disk(product, 61, 320, adiabatic=True), [30, 1, 1, 2, 9]
+        d.artificial_viscosity = B.ARTVISC_SN
+    else:
+        d, lengths = setups.planet_disk(product, 40, 263), [4, 100]
+        for s in (0, 1):
+            d.bc_sigma[s] = d.bc_energy[s] = d.bc_vrad[s] = d.bc_vaz[s] = B.BC_REFERENCE
+    bodies = setups.jupiter_bodies(d)
+    out = []
+    for explicit in (True, False):
+        ctx = driver.make_context(product, d, bodies=bodies)
+        if explicit:
+            ctx.set_transport_chunks(lengths)
+            tab = ctx.transport_chunks()
+            assert len(tab) >= len(lengths) - 1
+            # every ring exactly once
+            order = np.argsort(tab[:, 0])
+            assert tab[order[0], 0] == 0 and tab[order[-1], 1] == d.nr_global
+            assert np.array_equal(tab[order[1:], 0], tab[order[:-1], 1])
+            assert (tab[:, 1] > tab[:, 0]).all()
+        else:
+            ctx.set_option("transport_graded", 0)
+            assert len(ctx.transport_chunks()) == 0
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        assert ctx.run_steps(15) == 15
+        if explicit:
+            ctx.set_transport_chunks([])           # back to the built-in choice (equal chunks on a grid this small)
+            assert len(ctx.transport_chunks()) == 0
+        assert ctx.run_steps(4) == 4
+        c = ctx.clock
+        out.append((ctx.state(), (c.time, c.last_dt, c.n_hydro_iter)))
+        ctx.close()
+    assert out[0][1] == out[1][1]
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
+
+
 @pytest.mark.parametrize("nslabs", [1, 2])
 def test_cfl_thermal_option(product, oracle, nslabs, monkeypatch):
     """Option cfl_thermal (off by default: measured slower at 2048 x 4096): the marching transport stores the
