@@ -270,6 +270,15 @@ class Context:
             self._call("transport_chunks", out.ctypes.data_as(C.POINTER(_i32)), _i32(n.value), C.byref(n))
         return out
 
+    def source_chunks(self) -> np.ndarray:
+        """(segment, first ring, one past the last) of every wavefront of the marching source kernel, dispatch order; empty: equal chunks."""
+        n = _i32()
+        self._call("source_chunks", None, _i32(0), C.byref(n))
+        out = np.zeros((n.value, 3), dtype=np.int32)
+        if n.value:
+            self._call("source_chunks", out.ctypes.data_as(C.POINTER(_i32)), _i32(n.value), C.byref(n))
+        return out
+
     # radial slabs over RCCL inside the library
     def comm_init(self, unique_id: bytes):
         assert len(unique_id) == COMM_ID_BYTES

@@ -60,6 +60,7 @@ void options_from_environment(Options &o)
 {
     o.transport_fused = o.transport_rows = o.source_rows = o.theta_rows = -1;
     o.transport_graded = 1;
+    o.source_graded = -1;
     o.transport_big = o.transport_ladder = -1;
     o.transport_fallback = o.transport_split = o.fused_source = o.march_source = o.march_source_adi = 1;
     o.theta_march = o.theta_fused = o.cfl_rings = o.cfl_split = o.source_ring_parts = o.fused_damping = 1;
@@ -170,7 +171,20 @@ void apply_options(fcpt_ctx *c, bool at_create = true)
     c->cfl_interior = false;
     c->potential_valid = false;
     c->pressure_valid = false;
-    // the chunk table of the fused transport (the caller has synchronised the stream, or nothing has run yet)
+    // the wavefront table of the marching source kernels (the caller has synchronised the stream, or nothing has run yet)
+    c->P.sm_sched = nullptr;
+    c->P.sm_sched_n = 0;
+    c->sm_sched_host.clear();
+    if (c->sm_sched_dev && c->fused_source && c->march_source) {
+        const std::vector<int> sched = source_schedule(c->P);
+        if (!sched.empty() && sched.size() <= c->sm_sched_cap &&
+            hipMemcpy(c->sm_sched_dev, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
+            c->P.sm_sched = c->sm_sched_dev;
+            c->P.sm_sched_n = (int)(sched.size() / 4);
+            c->sm_sched_host = sched;
+        }
+    }
+    // the chunk table of the fused transport
     c->P.tf_sched = nullptr;
     c->P.tf_sched_n = 0;
     if (c->tf_sched_dev) {
@@ -673,6 +687,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         for (int i = 0; i < nr; ++i)
             c->ring_ref_damped[i] = (ty[0][i] == 1 || ty[1][i] == 1 || ty[2][i] == 1 || ty[3][i] == 1) ? 1 : 0;
         if (!rc) rc = dev_alloc(c, &c->tf_sched_dev, (size_t)2 * (nr + 8));
+        c->sm_sched_cap = (size_t)4 * (8 * 4 * 8 * 64 + 64); // one entry per wavefront slot of a 512-CU device at 8 per SIMD
+        if (!rc) rc = dev_alloc(c, &c->sm_sched_dev, c->sm_sched_cap);
         if (const char *q = getenv("FCPT_TF_SCHEDULE")) { // tuning runs: "28x56,12x24,6" = 56 chunks of 28 rings, 24 of 12, the rest of 6
             while (*q) {
                 char *e = nullptr;
@@ -807,6 +823,18 @@ int fcpt_transport_chunks(const fcpt_ctx *c, int32_t *first_last, int32_t capaci
         first_last[2 * k] = c->tf_sched_host[2 * k];
         first_last[2 * k + 1] = c->tf_sched_host[2 * k + 1];
     }
+    return FCPT_OK;
+}
+
+int fcpt_source_chunks(const fcpt_ctx *c, int32_t *seg_first_last, int32_t capacity, int32_t *n_wavefronts)
+{
+    if (!c || !n_wavefronts || capacity < 0 || (capacity > 0 && !seg_first_last))
+        return FCPT_EINVAL;
+    const int n = (int)(c->sm_sched_host.size() / 4);
+    *n_wavefronts = n;
+    for (int k = 0; k < n && k < capacity; ++k)
+        for (int q = 0; q < 3; ++q)
+            seg_first_last[3 * k + q] = c->sm_sched_host[4 * k + q];
     return FCPT_OK;
 }
 

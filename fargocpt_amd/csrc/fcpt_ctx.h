@@ -64,6 +64,9 @@ struct fcpt_ctx {
     bool thermal_valid = false;     // ... and it describes the current state (set by a marching-transport step)
     bool qdiff_valid = false;       // Dev::qdiff holds Q+ - Q- of the grids (written by the last kick's march)
     std::vector<int> ring_ref_damped; // per ring: 1 if the folded damping loads reference values there (costlier rings of the transport)
+    int *sm_sched_dev = nullptr;      // storage of Dev::sm_sched
+    size_t sm_sched_cap = 0;          // ... in ints
+    std::vector<int> sm_sched_host;
     int *tf_sched_dev = nullptr;      // storage of Dev::tf_sched (2 (nr + 8) ints)
     std::vector<int> tf_lengths;      // explicit chunk lengths in dispatch order (fcpt_set_transport_chunks; FCPT_TF_SCHEDULE at fcpt_create); empty: built-in
     std::vector<int> tf_sched_host;   // what Dev::tf_sched holds

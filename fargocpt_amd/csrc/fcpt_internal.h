@@ -138,7 +138,8 @@ struct Options {
     int transport_graded;   // 1: chunks of graded length, long ones first (transport_schedule()); 0: equal chunks
     int transport_big;      // graded: rings per chunk of the first round (-1: from the grid and the wavefront slots)
     int transport_ladder;   // graded: per cent of the previous length each further round of chunks gets (-1: built-in)
-    int source_rows;        // ... of k_source_march(_adi)
+    int source_rows;        // ... of k_source_march(_adi) (> 0: equal chunks of that many rings)
+    int source_graded;      // per cent by which the wavefronts a SIMD receives last get shorter chunks than those it receives first (source_schedule(); 0: equal chunks, -1: built-in)
     int theta_rows;         // ... of k_transport_theta_march
     int transport_fallback; // 1: the two-kernel transport is queued behind every k_transport_fused
     int transport_split;    // fcpt_step_device_begin may split the transport around the ghost exchange
@@ -161,7 +162,7 @@ struct Options {
     int profile_stride;     // fcpt_profile_start: every n-th launch of the selected kernels is timed (an event pair costs ~3 us of stream time)
 };
 #define FCPT_OPTION_NAMES                                                                                        \
-    X(transport_fused) X(transport_rows) X(transport_graded) X(transport_big) X(transport_ladder) X(source_rows) X(theta_rows) X(transport_fallback) X(transport_split)    \
+    X(transport_fused) X(transport_rows) X(transport_graded) X(transport_big) X(transport_ladder) X(source_rows) X(source_graded) X(theta_rows) X(transport_fallback) X(transport_split)    \
     X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_split)   \
     X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(bc_in_cfl) X(comm_overlap) X(comm_loopback) X(graph_steps) X(profile_stride)
 
@@ -214,6 +215,8 @@ struct Dev {
     const ThetaRow *theta_tab;
     ShiftRow *shift_tab;
     const DampRow *damp_tab;
+    const int *sm_sched;    // wavefronts of the marching source kernels in dispatch order: (segment, first ring, one past the last, 0)
+    int sm_sched_n;         // ... how many, a multiple of 4 (0: equal chunks of source_rows() rings)
     const int *tf_sched;    // chunks of k_transport_fused in dispatch order: (first ring, one past the last) pairs
     int tf_sched_n;         // ... how many (0: equal chunks of transport_rows() rings)
     int *shift_jump;        // set by k_transport_fused when |Nshift[i]-Nshift[i-1]| > 1 somewhere: the unfused kernels take over

@@ -70,6 +70,7 @@ struct TransportResult {
 enum { TRANSPORT_ALL = 0, TRANSPORT_EDGES = 1, TRANSPORT_INTERIOR = 2 };
 TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part = TRANSPORT_ALL);
 bool transport_can_split(const Dev &P, bool shear_safe);
+std::vector<int> source_schedule(const Dev &P);
 std::vector<int> transport_schedule(const Dev &P, const std::vector<int> &slow_rings, const std::vector<int> *lengths);
 void launch_shift_means(const Dev &P, hipStream_t st);
 void launch_massflow(const Dev &P, hipStream_t st);

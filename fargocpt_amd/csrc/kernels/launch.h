@@ -164,15 +164,19 @@ static int march_len(const Dev &P, int rows_full)
         rows >>= 1;
     return rows;
 }
+// wavefronts per SIMD of the source-march instantiation that will run: 6 (isothermal), 4 (with StabilizeViscosity; ideal
+// EOS), 2 (ideal EOS with cooling terms or StabilizeViscosity)
+static int source_occupancy(const Dev &P)
+{
+    const bool wide_adi = P.adiabatic && (P.stabilize || P.cooling_surface || P.cooling_beta || P.heating_star || P.accel_force);
+    return P.adiabatic ? (wide_adi ? 2 : 4) : (P.stabilize ? 4 : 6);
+}
 static int source_rows(const Dev &P)
 {
     if (P.opt.source_rows > 0)
         return P.opt.source_rows;
     const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
-    // wavefronts per SIMD of the instantiation that will run: 6 (isothermal), 4 (with StabilizeViscosity; ideal
-    // EOS), 2 (ideal EOS with cooling terms or StabilizeViscosity)
-    const bool wide_adi = P.adiabatic && (P.stabilize || P.cooling_surface || P.cooling_beta || P.heating_star || P.accel_force);
-    const int occ = P.adiabatic ? (wide_adi ? 2 : 4) : (P.stabilize ? 4 : 6);
+    const int occ = source_occupancy(P);
     const long slots = (long)device_cus() * 4 * occ;
     int r = 4;
     long best_cost = 0;
@@ -192,6 +196,73 @@ static int source_rows(const Dev &P)
             return r + dr;
     }
     return r;
+}
+// Rank-matched chunks for the marching source kernels: one entry (segment, first ring, one past the last, 0) per
+// wavefront, indexed by blockIdx.x * 4 + wavefront of the block, i.e. in the order of dispatch.
+//
+// Why: these kernels run as ONE round of wavefronts (the cheapest form: source_rows()), all starting together.  A SIMD
+// issues for its oldest wavefront first, and the dispatcher hands every CU of an XCD one workgroup before any gets its
+// second: the q-th wavefront an XCD receives sits at rank q / (4 x CUs) of its SIMD and advances at a rate that falls
+// with the rank -- the trace of k_source_march_adi at 2048 x 4096 (profiles/r03_sm_wave_trace_ideal_uniform.txt) shows
+// the four ranks ending at 125 / 135 / 152 / 172 us of 181, i.e. rates 1 : 0.92 : 0.79 : 0.65 while all four are resident,
+// and the GPU a third empty for the last 58 us.  Chunk lengths in proportion to the rate of the rank that will march them
+// ((rings + pre-roll) ~ 1 - g rank / (ranks - 1)) end all wavefronts together.
+// Every XCD keeps a contiguous eighth of the rings (its L2 serves the shared halo cells); within it every segment
+// (column of 59 cells) is cut into as many chunks as fit the XCD's slots once, and the chunks of the columns are dealt
+// to the dispatch order in a snake (0 .. segs-1, segs-1 .. 0, ...) so that every column gets nearly the same mix of ranks.
+// Empty where equal chunks stay: source_rows > 0, source_graded = 0, more than one round, chains beyond 64 rings.
+std::vector<int> source_schedule(const Dev &P)
+{
+    std::vector<int> out;
+    if (P.nphi < 128 || P.opt.source_rows > 0 || P.opt.source_graded == 0)
+        return out;
+    const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
+    const int occ = source_occupancy(P);
+    const int wpr = device_cus() / 8 * 4; // wavefronts of one rank in an XCD: one per SIMD
+    const int rows = P.nr + 1;            // v_r has rows 0 .. nr
+    const int PRE = 4;
+    if (wpr < 4 || occ < 2 || rows < 64)
+        return out;
+    int cpc = wpr * occ / segs; // chunks per column in an XCD's eighth of the rings
+    if (cpc < 2)
+        return out;
+    const int rx = rows / 8;
+    if (cpc > rx / 6)
+        return out; // short chunks: the grid does not fill the slots once (source_rows() picks the shortest equal chunks)
+    if ((rx + 1 + cpc - 1) / cpc > 64)
+        return out; // one round would be chains longer than any measured: several rounds of equal chunks
+    const double g = (P.opt.source_graded > 0 && P.opt.source_graded < 100 ? P.opt.source_graded : (P.adiabatic ? 35 : 20)) * 0.01;
+    std::vector<double> w(occ);
+    for (int r = 0; r < occ; ++r)
+        w[r] = 1.0 - g * r / (occ - 1);
+    const int nblk = (cpc * segs + 3) / 4; // workgroups per XCD
+    out.assign((size_t)nblk * 8 * 4 * 4, 0);
+    for (int x = 0; x < 8; ++x) {
+        const int A = (int)((long)x * rows / 8), B = (int)((long)(x + 1) * rows / 8), n = B - A;
+        for (int c = 0; c < segs; ++c) {
+            double sw = 0.0;
+            for (int j = 0; j < cpc; ++j) {
+                const int q = j * segs + ((j & 1) ? segs - 1 - c : c);
+                sw += w[q / wpr < occ ? q / wpr : occ - 1];
+            }
+            const double scale = (n + (double)cpc * PRE) / sw;
+            double edge = 0.0;
+            int k0 = A;
+            for (int j = 0; j < cpc; ++j) {
+                const int q = j * segs + ((j & 1) ? segs - 1 - c : c);
+                edge += scale * w[q / wpr < occ ? q / wpr : occ - 1] - PRE;
+                int k1 = j == cpc - 1 ? B : A + (int)(edge + 0.5);
+                if (k1 < k0 + 3 || k1 > B) { // (cannot happen with the bounds above; equal chunks rather than a wrong table)
+                    out.clear();
+                    return out;
+                }
+                const size_t t = ((size_t)(q / 4) * 8 + x) * 4 + (q & 3);
+                out[4 * t] = c, out[4 * t + 1] = k0, out[4 * t + 2] = k1;
+                k0 = k1;
+            }
+        }
+    }
+    return out;
 }
 // Chunks of graded length for k_transport_fused, in dispatch order: (first ring, one past the last) pairs.
 //
@@ -318,11 +389,12 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
     if ((long long)(P.nr + 1) * P.nphi >= (1ll << 29))
         return 0; // the kernels address cells by 32-bit byte offsets (ld_off): grids below 4 GiB
     int bc_fold = 0;
+    const bool sched = P.sm_sched_n > 0 && P.opt.source_rows <= 0; // rank-matched chunks (every one of them >= 3 rings)
     {
         // the boundary conditions read rows 1, 2 and nr-2 .. nr of the kick's result: the wavefront that applies them
         // must have stored those rows itself
-        const int rows = source_rows(P), chunks = (P.nr + 1 + rows - 1) / rows;
-        const int last_rows = (P.nr + 1) - (chunks - 1) * rows;
+        const int rows = sched ? 3 : source_rows(P), chunks = (P.nr + 1 + rows - 1) / rows;
+        const int last_rows = sched ? 3 : (P.nr + 1) - (chunks - 1) * rows;
         if (fold_bc && P.opt.bc_fold != 0 && rows >= 3 && last_rows >= 3 && P.nr >= 6 && (!P.adiabatic || P.opt.march_source_adi != 0)) {
             bc_fold = 1;
             if (bc_folded)
@@ -335,7 +407,7 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
         const int rows = source_rows(P);
         const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
         const int chunks = (P.nr + 1 + rows - 1) / rows;
-        const dim3 grid((segs * chunks + 3) / 4), block(256);
+        const dim3 grid(sched ? P.sm_sched_n / 4 : (segs * chunks + 3) / 4), block(256);
         const bool cool = P.cooling_surface != 0 || P.cooling_beta != 0 || P.heating_star != 0;
         const int ring_sums = segs <= P.ring_pstride && P.opt.source_ring_parts != 0;
 #define ADIKS(AV_, COOL_, POT_)                                                                                               \
@@ -388,7 +460,7 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
     // instead of the ring itself
     const int ring_sums = segs <= P.ring_pstride && P.opt.source_ring_parts != 0;
     const int chunks = (P.nr + 1 + rows - 1) / rows;
-    const int waves = segs * chunks;
+    const int waves = sched ? P.sm_sched_n : segs * chunks;
     const dim3 grid((waves + 3) / 4), block(256);
 #define ISOKA(AV_, ACC_)                                                                                    \
     if (P.stabilize)                                                                                        \

@@ -91,21 +91,37 @@ __device__ __forceinline__ double visc_corr_march(double dt, double c) { return 
 // ACC: BodyForceFromPotential: no -- the window carries ACCEL_RADIAL (in the potential's place) and ACCEL_AZIMUTHAL of
 // CalculateAccelOnGas instead of the potential (SourceEuler.cpp:348-353, 406-411)
 template <int AV, bool STAB, bool ACC = false> // AV 0: none, 1: TW, 2: SN
-#ifdef SM_TRACE /* profiles/tools/wave_trace.py: the wavefronts' end times, at the production occupancy */
+#ifdef SM_TRACE /* (the trace must run at the production occupancy) */
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 #else
 __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 #endif
 {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int chunk = wave / segs;
-    const int seg = wave - chunk * segs;
     const int nr = P.nr, nphi = P.nphi;
-    const int k0 = chunk * rows_per_chunk;
-    if (k0 > nr)
-        return;
-    const int k1 = (k0 + rows_per_chunk < nr + 1) ? k0 + rows_per_chunk : nr + 1; // v_r has rows 0..nr
+    int wave, seg, k0, k1;
+    if (P.sm_sched) { // (segment, first ring, one past the last) of every wavefront in the order of dispatch: source_schedule()
+        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        const int __attribute__((address_space(4))) *e = (const int __attribute__((address_space(4))) *)P.sm_sched + 4 * wave;
+        seg = e[0], k0 = e[1], k1 = e[2];
+        if (k0 >= k1)
+            return;
+    } else {
+        wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        const int chunk = wave / segs;
+        seg = wave - chunk * segs;
+        k0 = chunk * rows_per_chunk;
+        if (k0 > nr)
+            return;
+        k1 = (k0 + rows_per_chunk < nr + 1) ? k0 + rows_per_chunk : nr + 1; // v_r has rows 0..nr
+    }
+#ifdef SM_TRACE /* profiles/tools/wave_trace_source.py: start, end (10 ns ticks), first ring, one past the last of every wavefront */
+    if (lane == 0) {
+        P.temperature[4 * wave] = (double)wall_clock64(); // (a grid neither marching kernel touches)
+        P.temperature[4 * wave + 2] = (double)k0;
+        P.temperature[4 * wave + 3] = (double)k1;
+    }
+#endif
     const int jraw = seg * MARCH_VALID - MARCH_LO + lane;
     const int j = jraw < 0 ? jraw + nphi : (jraw >= nphi ? jraw - nphi : jraw);
     const bool store_lane = lane >= MARCH_LO && lane < MARCH_LO + MARCH_VALID && jraw < nphi;
@@ -335,7 +351,7 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
     }
 #ifdef SM_TRACE
     if (lane == 0)
-        P.temperature[2 * wave + 1] = (double)wall_clock64(); // 10 ns ticks; the isothermal path does not use the grid
+        P.temperature[4 * wave + 1] = (double)wall_clock64();
 #endif
 #undef NEXT
 #undef PREV
@@ -362,14 +378,30 @@ template <int AV, bool COOL, bool POT, bool STAB, bool ACC = false> // AV 0: non
 __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int chunk = wave / segs;
-    const int seg = wave - chunk * segs;
     const int nr = P.nr, nphi = P.nphi;
-    const int k0 = chunk * rows_per_chunk;
-    if (k0 > nr)
-        return;
-    const int k1 = (k0 + rows_per_chunk < nr + 1) ? k0 + rows_per_chunk : nr + 1; // v_r has rows 0..nr
+    int wave, seg, k0, k1;
+    if (P.sm_sched) { // (segment, first ring, one past the last) of every wavefront in the order of dispatch: source_schedule()
+        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        const int __attribute__((address_space(4))) *e = (const int __attribute__((address_space(4))) *)P.sm_sched + 4 * wave;
+        seg = e[0], k0 = e[1], k1 = e[2];
+        if (k0 >= k1)
+            return;
+    } else {
+        wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        const int chunk = wave / segs;
+        seg = wave - chunk * segs;
+        k0 = chunk * rows_per_chunk;
+        if (k0 > nr)
+            return;
+        k1 = (k0 + rows_per_chunk < nr + 1) ? k0 + rows_per_chunk : nr + 1; // v_r has rows 0..nr
+    }
+#ifdef SM_TRACE /* profiles/tools/wave_trace_source.py: start, end (10 ns ticks), first ring, one past the last of every wavefront */
+    if (lane == 0) {
+        P.temperature[4 * wave] = (double)wall_clock64(); // (a grid neither marching kernel touches)
+        P.temperature[4 * wave + 2] = (double)k0;
+        P.temperature[4 * wave + 3] = (double)k1;
+    }
+#endif
     const int jraw = seg * MARCH_VALID - MARCH_LO + lane;
     const int j = jraw < 0 ? jraw + nphi : (jraw >= nphi ? jraw - nphi : jraw);
     const bool store_lane = lane >= MARCH_LO && lane < MARCH_LO + MARCH_VALID && jraw < nphi;
@@ -714,6 +746,10 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
             boundary_column(Q, j, sides);
         }
     }
+#ifdef SM_TRACE
+    if (lane == 0)
+        P.temperature[4 * wave + 1] = (double)wall_clock64();
+#endif
 #undef NEXT
 #undef PREV
 }

@@ -310,7 +310,7 @@ int fcpt_synchronize(fcpt_ctx *ctx);
 /* Kernel-selection switches of one context, by name (lower case, e.g. "transport_fallback"): which of the
  * parity-tested kernel variants the step uses, marching-chunk lengths, overlap of the ghost exchange.  The
  * environment variables FCPT_<NAME> only provide the defaults read once in fcpt_create; no launch reads the
- * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows, transport_graded, transport_big, transport_ladder,
+ * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows, transport_graded, transport_big, transport_ladder, source_graded,
  * source_rows, theta_rows, transport_fallback, transport_split, fused_source, march_source, march_source_adi,
  * theta_march, theta_fused, cfl_rings, cfl_split, source_ring_parts, fused_damping, inline_potential, cfl_thermal, bc_fold, bc_in_cfl, comm_overlap,
  * comm_loopback, graph_steps, profile_stride (fcpt_profile_start times every n-th launch of the selected kernels).
@@ -332,6 +332,12 @@ int fcpt_get_option(const fcpt_ctx *ctx, const char *name, int32_t *value);
  * (No counterpart in the reference: its loops are not chunked.) */
 int fcpt_set_transport_chunks(fcpt_ctx *ctx, const int32_t *lengths, int32_t n);
 int fcpt_transport_chunks(const fcpt_ctx *ctx, int32_t *first_last, int32_t capacity, int32_t *n_chunks);
+/* Likewise the marching kernels of the source step (update_with_sourceterms ... SubStep3 as one pass, src/SourceEuler.cpp,
+ * src/viscosity/): where one round of wavefronts covers the slab, every wavefront's chunk length is matched to the rate at
+ * which its SIMD will serve it (option source_graded, per cent of difference between first and last rank; 0: equal
+ * chunks).  Reports (segment of 59 cells, first ring, one past the last ring) per wavefront in the order of dispatch,
+ * entries with first == last being idle; n_wavefronts = 0: equal chunks of source_rows rings. */
+int fcpt_source_chunks(const fcpt_ctx *ctx, int32_t *seg_first_last, int32_t capacity, int32_t *n_wavefronts);
 
 int fcpt_get_split(const fcpt_ctx *ctx, fcpt_split *out);
 int fcpt_get_clock(const fcpt_ctx *ctx, fcpt_clock *out);

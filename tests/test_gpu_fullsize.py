@@ -226,3 +226,46 @@ def test_graded_transport_chunks_at_full_size(product, adiabatic):
     assert out[0][1] == out[1][1]
     for k in out[0][0]:
         assert np.array_equal(out[0][0][k], out[1][0][k]), k
+
+
+@pytest.mark.parametrize("adiabatic", [False, True])
+def test_rank_matched_source_chunks_at_full_size(product, adiabatic):
+    """The marching source kernels run as one round of wavefronts at the bench size; the library matches every
+    wavefront's chunk length to the rank at which its SIMD will serve it (source_schedule in kernels/launch.h).  The
+    table must hold every (segment, ring) exactly once, give the first wavefronts of an XCD longer chunks than its last,
+    and give the bits of equal chunks (every ring of a segment is computed by one wavefront from the same operands; the
+    ring sums of v_phi are per segment)."""
+    d = setups.planet_disk(product, NR, NPHI, adiabatic=adiabatic)
+    d0 = d.copy()
+    radii = product.radii(d0)
+    fields = perturb(product.initial_fields(d0, radii), d0, 1e-3)
+    bodies = setups.jupiter_bodies(d0)
+    out = []
+    for graded in (-1, 0):
+        ctx = driver.make_context(product, d0, fields=fields, radii=radii, bodies=bodies)
+        ctx.set_option("source_graded", graded)
+        tab = ctx.source_chunks()
+        if graded:
+            segs = (NPHI + 58) // 59
+            assert len(tab) % 4 == 0 and len(tab) >= segs * 8
+            live = tab[tab[:, 2] > tab[:, 1]]
+            cover = np.zeros((segs, NR + 1), dtype=np.int32)
+            for sg, k0, k1 in live:
+                cover[sg, k0:k1] += 1
+            assert (cover == 1).all()
+            n = live[:, 2] - live[:, 1]
+            assert n.min() >= 3
+            xcd0 = tab[(np.arange(len(tab)) // 4) % 8 == 0]          # workgroups 0, 8, 16, ... = dispatch order of XCD 0
+            xcd0 = xcd0[xcd0[:, 2] > xcd0[:, 1]]
+            m = xcd0[:, 2] - xcd0[:, 1]
+            assert m[:64].mean() > 1.1 * m[-64:].mean()
+        else:
+            assert len(tab) == 0
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        assert ctx.run_steps(12) == 12
+        out.append((ctx.state(), ctx.clock.time))
+        ctx.close()
+    assert out[0][1] == out[1][1]
+    for k in out[0][0]:
+        assert np.array_equal(out[0][0][k], out[1][0][k]), k
