@@ -101,13 +101,43 @@ __device__ __forceinline__ bool cfl_last_workgroup(int *tickets, int b, int nb);
 // (P BY VALUE, as a kernel's own argument: with `const Dev &P` the scheduler hoists the loads of all eight cell pairs of
 //  the 256-thread form -- 224 instead of 100 registers, two instead of four wavefronts per SIMD -- and the ideal-EOS
 //  launch takes 97 instead of 74 us: occupancy beats loads in flight per thread here)
-template <bool ADI, int MAXP, int NT> __device__ __forceinline__ void cfl_ring_block(const Dev P, double *part, const int i)
+// HOIST (the 1024-thread forms, two cell pairs per thread): everything else a cell pair needs -- v_r of rings i and i+1,
+// v_phi of cell j+2, and for the ideal EOS e, Sigma, Q+ - Q- -- is loaded TOGETHER with v_phi, ahead of the ring
+// sum and its barrier, which none of it depends on: one memory round trip per workgroup instead of two.
+struct CflPair {
+    D2 r0, r1, e2, s2, qp, qm, th;
+    double van1;
+};
+template <bool ADI> __device__ __forceinline__ CflPair cfl_load_pair(const Dev &P, size_t row, int nphi, int j)
+{
+    CflPair d;
+    d.r0 = *(const D2 *)(P.vrad + row + j), d.r1 = *(const D2 *)(P.vrad + row + nphi + j);
+    d.van1 = P.vazi[row + (j + 2 >= nphi ? 0 : j + 2)]; // v_phi of cell j+2
+    d.e2 = D2{0.0, 0.0}, d.s2 = D2{1.0, 1.0}, d.qp = D2{0.0, 0.0}, d.qm = D2{0.0, 0.0}, d.th = D2{0.0, 0.0};
+    const bool thermal = ADI && P.cfl_thermal_on != 0; // invdt1^2 + invdt5^2 + invdt6^2 left by the transport
+    if (thermal) {
+        d.th = *(const D2 *)(P.cfl_thermal + row + j);
+    } else if (ADI) {
+        d.e2 = *(const D2 *)(P.energy + row + j);
+        d.s2 = *(const D2 *)(P.sigma + row + j);
+        if (P.qdiff_on) { // Q+ - Q- as one grid, left by the source march
+            d.qp = *(const D2 *)(P.qdiff + row + j);
+        } else {
+            d.qp = *(const D2 *)(P.qplus + row + j);
+            d.qm = *(const D2 *)(P.qminus + row + j);
+        }
+    }
+    return d;
+}
+template <bool ADI, int MAXP, int NT, bool HOIST = false> __device__ __forceinline__ void cfl_ring_block(const Dev P, double *part, const int i)
 {
     constexpr int NW = NT / 64;
     const int nphi = P.nphi, npair = nphi >> 1;
     const int t = threadIdx.x;
     const size_t row = (size_t)i * nphi;
+    const bool active = i >= P.first_active && i < P.active_size;
     D2 va[MAXP];
+    CflPair pd[HOIST ? MAXP : 1];
     double acc = 0.0, acc2 = 0.0;
 #pragma unroll
     for (int n = 0; n < MAXP; ++n) {
@@ -115,6 +145,8 @@ template <bool ADI, int MAXP, int NT> __device__ __forceinline__ void cfl_ring_b
         va[n] = D2{0.0, 0.0};
         if (p < npair)
             va[n] = *(const D2 *)(P.vazi + row + 2 * p);
+        if (HOIST && active && p < npair)
+            pd[n] = cfl_load_pair<ADI>(P, row, nphi, 2 * p);
     }
 #pragma unroll
     for (int n = 0; n < MAXP; ++n) {
@@ -136,7 +168,7 @@ template <bool ADI, int MAXP, int NT> __device__ __forceinline__ void cfl_ring_b
     if (t == 0)
         P.vmean[i] = mean;
     double s = 0.0;
-    if (i >= P.first_active && i < P.active_size) {
+    if (active) {
         const double lf = P.leapfrog ? 0.6 : 1.0;
         const double C2 = P.art_visc_factor * P.art_visc_factor;
         const double inv_dxr = P.InvDiffRsup[i];         // 1 / (Rsup - Rinf)
@@ -154,22 +186,10 @@ template <bool ADI, int MAXP, int NT> __device__ __forceinline__ void cfl_ring_b
             const int p = t + n * NT;
             if (p < npair) {
                 const int j = 2 * p;
-                const D2 r0 = *(const D2 *)(P.vrad + row + j), r1 = *(const D2 *)(P.vrad + row + nphi + j);
-                const double van1 = P.vazi[row + (j + 2 >= nphi ? 0 : j + 2)]; // v_phi of cell j+2
-                D2 e2 = {0.0, 0.0}, s2 = {1.0, 1.0}, qp = {0.0, 0.0}, qm = {0.0, 0.0}, th = {0.0, 0.0};
-                const bool thermal = ADI && P.cfl_thermal_on != 0; // invdt1^2 + invdt5^2 + invdt6^2 left by the transport
-                if (thermal) {
-                    th = *(const D2 *)(P.cfl_thermal + row + j);
-                } else if (ADI) {
-                    e2 = *(const D2 *)(P.energy + row + j);
-                    s2 = *(const D2 *)(P.sigma + row + j);
-                    if (P.qdiff_on) { // Q+ - Q- as one grid, left by the source march
-                        qp = *(const D2 *)(P.qdiff + row + j);
-                    } else {
-                        qp = *(const D2 *)(P.qplus + row + j);
-                        qm = *(const D2 *)(P.qminus + row + j);
-                    }
-                }
+                const CflPair d = HOIST ? pd[HOIST ? n : 0] : cfl_load_pair<ADI>(P, row, nphi, j);
+                const D2 r0 = d.r0, r1 = d.r1, e2 = d.e2, s2 = d.s2, qp = d.qp, qm = d.qm, th = d.th;
+                const double van1 = d.van1;
+                const bool thermal = ADI && P.cfl_thermal_on != 0;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double vr0 = c ? r0.y : r0.x, vr1 = c ? r1.y : r1.x;
@@ -230,7 +250,7 @@ template <bool ADI, int MAXP, int NT = 256> __global__ void CFL_RINGS_ATTR k_cfl
 {
     const int b = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
     const int i = b < n1 ? r1 + b : r2 + (b - n1);
-    cfl_ring_block<ADI, MAXP, NT>(P, part, i);
+    cfl_ring_block<ADI, MAXP, NT, (NT >= 1024)>(P, part, i);
     if (finalize && cfl_last_workgroup(P.cfl_tickets, blockIdx.x, gridDim.x))
         cfl_fold(P, part, P.nr, finalize - 1);
 }
@@ -271,7 +291,7 @@ template <bool ADI, int MAXP, int NT = 256> __global__ void CFL_RINGS_ATTR k_cfl
         while (__hip_atomic_load(flag + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq)
             __builtin_amdgcn_s_sleep(2);
     }
-    cfl_ring_block<ADI, MAXP, NT>(P, part, i);
+    cfl_ring_block<ADI, MAXP, NT, (NT >= 1024)>(P, part, i);
 }
 // The last step of the reduction by one workgroup: fold the partial maxima, add the FARGO shear limit, leave the
 // result in the device clock (and apply the CalculateTimeStep policy for device-resident loops).

@@ -820,6 +820,14 @@ bool cfl_by_rings(const Dev &P)
     return (P.nphi & 1) == 0 && P.nphi >= 128 && P.nphi <= 1024 * CFL_MAXP && (!P.adiabatic || P.lazy_derived) &&
            P.stabilize != 2 && P.opt.cfl_rings != 0;
 }
+// rings of 2049 .. 4096 cells: 1024 threads with two cell pairs each and ALL their loads ahead of the ring sum, instead
+// of 256 with eight.  Isothermal (two grids): 37 -> 33 us at 2048 x 4096 (profiles/r03_ab_cfl_threads.txt).  Ideal EOS
+// (five grids, 100 VGPRs = one 1024-thread workgroup per CU): 65 against 52 us in the bench's units, 0.505-0.508
+// against 0.491-0.496 ms per step (profiles/r03_ab_cfl_hoist.txt) -- it keeps the 256-thread form.
+static bool cfl_wide_blocks(const Dev &P)
+{
+    return P.opt.cfl_wide_blocks < 0 ? !P.adiabatic : P.opt.cfl_wide_blocks != 0;
+}
 static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, int finalize, hipStream_t st)
 {
     if (n1 + n2 <= 0)
@@ -834,11 +842,11 @@ static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, int f
         return;
     }
 #endif
-    // isothermal rings of 2049 .. 4096 cells: 1024 threads with two cell pairs each instead of 256 with eight (all of
-    // a thread's loads in flight at once: 37 -> 33 us at 2048 x 4096, two A/B pairs, profiles/r03_ab_cfl_threads.txt;
-    // the ideal-EOS instantiation -- five grids, 4.5 TB/s -- is indifferent to it: 74.5 us either way)
-    if (!P.adiabatic && !wide && P.nphi > 2048) {
-        KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, CFL_MAXP / 4, 1024>), dim3(n1 + n2), dim3(1024), P, P.cfl_part, r1, n1, r2, finalize);
+    if (!wide && P.nphi > 2048 && cfl_wide_blocks(P)) {
+        if (P.adiabatic)
+            KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<true, CFL_MAXP / 4, 1024>), dim3(n1 + n2), dim3(1024), P, P.cfl_part, r1, n1, r2, finalize);
+        else
+            KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, CFL_MAXP / 4, 1024>), dim3(n1 + n2), dim3(1024), P, P.cfl_part, r1, n1, r2, finalize);
         return;
     }
     if (P.adiabatic && wide)
@@ -866,8 +874,12 @@ void launch_cfl_bc(const Dev &P, int apply_policy, hipStream_t st)
 #define CFLBC(ADI_, MAXP_, NT_)                                                                                              \
     KLAUNCH(KID_CFL_RINGS_BC, (k_cfl_rings_bc<ADI_, MAXP_, NT_>), dim3((P.nphi + NT_ - 1) / NT_ + P.nr), dim3(NT_), P, P.cfl_part, \
             (P.nphi + NT_ - 1) / NT_)
-    if (!P.adiabatic && !wide && P.nphi > 2048) {
-        CFLBC(false, CFL_MAXP / 4, 1024);
+    if (!wide && P.nphi > 2048 && cfl_wide_blocks(P)) {
+        if (P.adiabatic) {
+            CFLBC(true, CFL_MAXP / 4, 1024);
+        } else {
+            CFLBC(false, CFL_MAXP / 4, 1024);
+        }
     } else if (P.adiabatic && wide) {
         CFLBC(true, 2 * CFL_MAXP, 256);
     } else if (P.adiabatic) {
