@@ -191,6 +191,17 @@ class Library:
                    "selftest_half_limiter")
         return out
 
+    def selftest_chunk_tables(self, nr: int, nphi: int, n_cu: int = 256, adiabatic: bool = False, damp_inner: int = 0, damp_outer: int = 0):
+        """(transport chunks [n, 2], source wavefronts [m, 3]) the library would use for such a slab and device: host logic, no GPU."""
+        nt, ns = _i32(), _i32()
+        f = self.fn("selftest_chunk_tables")
+        args = (_i32(nr), _i32(nphi), _i32(n_cu), _i32(int(adiabatic)), _i32(damp_inner), _i32(damp_outer))
+        self.check(f(*args, None, _i32(0), C.byref(nt), None, _i32(0), C.byref(ns)), "selftest_chunk_tables")
+        t, s = np.zeros((nt.value, 2), dtype=np.int32), np.zeros((ns.value, 3), dtype=np.int32)
+        self.check(f(*args, t.ctypes.data_as(C.POINTER(_i32)), _i32(nt.value), C.byref(nt),
+                     s.ctypes.data_as(C.POINTER(_i32)), _i32(ns.value), C.byref(ns)), "selftest_chunk_tables")
+        return t, s
+
     def comm_unique_id(self) -> bytes:
         """ncclGetUniqueId: slab 0 calls it and hands the bytes to every slab (fcpt_comm_init)."""
         buf = C.create_string_buffer(COMM_ID_BYTES)

@@ -1193,6 +1193,28 @@ int fcpt_selftest_half_limiter(int32_t limiter, int64_t n, const double *a, cons
     return rc;
 }
 
+// test hook: the chunk tables of the marching kernels as pure host logic
+int fcpt_selftest_chunk_tables(int32_t nr, int32_t nphi, int32_t n_cu, int32_t adiabatic, int32_t damp_inner, int32_t damp_outer,
+                               int32_t *transport_first_last, int32_t transport_capacity, int32_t *n_transport,
+                               int32_t *source_seg_first_last, int32_t source_capacity, int32_t *n_source)
+{
+    if (nr < 1 || nphi < 1 || n_cu < 8 || damp_inner < 0 || damp_outer < 0 || !n_transport || !n_source || transport_capacity < 0 ||
+        source_capacity < 0 || (transport_capacity > 0 && !transport_first_last) || (source_capacity > 0 && !source_seg_first_last))
+        return FCPT_EINVAL;
+    Options opt;
+    options_from_environment(opt);
+    std::vector<int> t, s;
+    selftest_chunk_tables(nr, nphi, n_cu, adiabatic != 0, damp_inner, damp_outer, opt, t, s);
+    *n_transport = (int32_t)(t.size() / 2);
+    *n_source = (int32_t)(s.size() / 4);
+    for (int k = 0; k < *n_transport && k < transport_capacity; ++k)
+        transport_first_last[2 * k] = t[2 * k], transport_first_last[2 * k + 1] = t[2 * k + 1];
+    for (int k = 0; k < *n_source && k < source_capacity; ++k)
+        for (int q = 0; q < 3; ++q)
+            source_seg_first_last[3 * k + q] = s[4 * k + q];
+    return FCPT_OK;
+}
+
 int32_t fcpt_kernel_count(void) { return KID_COUNT; }
 const char *fcpt_kernel_name(int32_t id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
 

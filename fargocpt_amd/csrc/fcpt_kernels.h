@@ -71,6 +71,8 @@ enum { TRANSPORT_ALL = 0, TRANSPORT_EDGES = 1, TRANSPORT_INTERIOR = 2 };
 TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part = TRANSPORT_ALL);
 bool transport_can_split(const Dev &P, bool shear_safe);
 std::vector<int> source_schedule(const Dev &P);
+void selftest_chunk_tables(int nr, int nphi, int n_cu, int adiabatic, int damp_inner, int damp_outer, const Options &opt,
+                           std::vector<int> &transport, std::vector<int> &source);
 std::vector<int> transport_schedule(const Dev &P, const std::vector<int> &slow_rings, const std::vector<int> *lengths);
 void launch_shift_means(const Dev &P, hipStream_t st);
 void launch_massflow(const Dev &P, hipStream_t st);

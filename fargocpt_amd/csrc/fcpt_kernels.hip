@@ -10,6 +10,7 @@
 
 #include <cstddef>
 #include <cstdlib>
+#include <cstring>
 
 #include "fcpt_kernels.h"
 

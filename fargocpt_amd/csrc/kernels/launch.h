@@ -137,8 +137,11 @@ void launch_source_fused(const Dev &P, hipStream_t st)
 //   transport: see transport_rows().
 // Small grids have fewer wavefronts than slots at any length: the shortest chunks (4 rings) win there.
 // compute units of the current device (one device per process)
+static int g_cus_override = 0; // fcpt_selftest_chunk_tables: the host logic for a device of that many CUs
 static int device_cus()
 {
+    if (g_cus_override > 0)
+        return g_cus_override;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0, v = 0;
@@ -345,6 +348,23 @@ std::vector<int> transport_schedule(const Dev &P, const std::vector<int> &slow, 
         }
     }
     return out;
+}
+// test hook (no GPU needed): the two tables for a grid, an EOS and a device of n_cu compute units; the first
+// damp_inner and the last damp_outer rings load reference values in the transport (damping zones)
+void selftest_chunk_tables(int nr, int nphi, int n_cu, int adiabatic, int damp_inner, int damp_outer, const Options &opt,
+                           std::vector<int> &transport, std::vector<int> &source)
+{
+    Dev P;
+    std::memset(&P, 0, sizeof(P));
+    P.nr = nr, P.nphi = nphi, P.adiabatic = adiabatic, P.opt = opt;
+    P.damp_in_step = (damp_inner > 0 || damp_outer > 0) ? 1 : 0;
+    std::vector<int> slow(nr > 0 ? nr : 0, 0);
+    for (int i = 0; i < nr; ++i)
+        slow[i] = (i < damp_inner || i >= nr - damp_outer) ? 1 : 0;
+    g_cus_override = n_cu;
+    transport = transport_schedule(P, slow, nullptr);
+    source = source_schedule(P);
+    g_cus_override = 0;
 }
 // The transport deals whole chunks to the 8 XCDs (k_transport_fused), so the rounds are counted per XCD; and its
 // chunks are not equal: the rings of the damping zones (folded into the kernel) cost ~1.5x and are started first, which

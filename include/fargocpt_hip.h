@@ -545,6 +545,12 @@ const char *fcpt_kernel_name(int32_t id);
 int fcpt_profile_start(fcpt_ctx *ctx, uint64_t mask, int32_t max_launches);
 int fcpt_profile_stop(fcpt_ctx *ctx, double *ms_total, int64_t *launches);
 
+/* Test hook, needs no GPU: the tables fcpt_transport_chunks / fcpt_source_chunks would report for a slab of nr x nphi
+ * cells on a device of n_cu compute units (8 XCDs), isothermal or ideal EOS, with damping zones of damp_inner / damp_outer
+ * rings folded into the transport.  n_transport / n_source = 0: equal chunks (small grids, rings of > 8192 cells ...). */
+int fcpt_selftest_chunk_tables(int32_t nr, int32_t nphi, int32_t n_cu, int32_t adiabatic, int32_t damp_inner, int32_t damp_outer,
+                               int32_t *transport_first_last, int32_t transport_capacity, int32_t *n_transport,
+                               int32_t *source_seg_first_last, int32_t source_capacity, int32_t *n_source);
 /* Test hook: out[k] = 0.5 * flux_limiter(a[k], b[k]) (src/TransportEuler.cpp:306-337; limiter = FCPT_LIMITER_*) exactly
  * as the transport kernels evaluate it on the device -- the van Leer form there is branch-free (max(ab, 0) times a
  * guarded reciprocal of a + b) and its edge cases (+-0, denormal and cancelling sums) are what this call lets a test

@@ -236,3 +236,41 @@ def test_rank_launcher_of_the_host_driver_reports_and_cleans_up(tmp_path):
     cfg.write_text(f"Nrad: 64\nNazz: 64\nOutputDir: {tmp_path}/out\n")
     r = subprocess.run([exe, "--ranks", "2", "start", str(cfg)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "Unknown key(s) found in config file: 'nazz'" in r.stderr and "no HIP device" not in r.stderr
+
+
+@pytest.mark.parametrize("nr,nphi,adiabatic,damp", [(2048, 4096, False, 100), (2048, 4096, True, 100), (2048, 6144, False, 0),
+                                                    (1024, 3072, True, 50), (4096, 4096, False, 0), (1367, 2731 * 2, True, 33),
+                                                    (512, 1536, False, 20), (128, 384, False, 0), (100, 2, False, 0)])
+def test_chunk_tables_of_the_marching_kernels(product, nr, nphi, adiabatic, damp):
+    """transport_schedule / source_schedule (kernels/launch.h) as host logic for an MI355X (256 CUs): whatever the
+    grid, a table that is handed to the kernels holds every ring (every (segment, ring)) exactly once, no chunk is
+    empty, the long chunks come first; small grids get no table (equal chunks)."""
+    t, s = product.selftest_chunk_tables(nr, nphi, 256, adiabatic, damp, damp)
+    if len(t):
+        order = np.argsort(t[:, 0])
+        assert t[order[0], 0] == 0 and t[order[-1], 1] == nr
+        assert np.array_equal(t[order[1:], 0], t[order[:-1], 1])
+        n = t[:, 1] - t[:, 0]
+        assert n.min() >= 1
+        k0 = 8 * -(-512 // -(-nphi // 53))            # 8 * ceil(slots per XCD / tiles): the first level
+        assert len(t) > k0 and n[k0 - 8:k0].min() >= 2 * n[-9:-1].max()
+        if damp:                                        # a damping-zone ring counts 1.4: those chunks hold fewer rings
+            assert n[0] < n[k0 - 1]
+    if len(s):
+        segs = -(-nphi // 59)
+        assert len(s) % 32 == 0                         # whole workgroups, the same number for each of the 8 XCDs
+        live = s[s[:, 2] > s[:, 1]]
+        cover = np.zeros((segs, nr + 1), dtype=np.int32)
+        for sg, a, b in live:
+            cover[sg, a:b] += 1
+        assert (cover == 1).all()
+        assert (live[:, 2] - live[:, 1]).min() >= 3     # the boundary call folded into the kick needs three rows
+        per_xcd = len(s) // 8
+        assert len(live) <= 256 * 4 * (4 if adiabatic else 6)   # one round of wavefronts
+        x0 = s[(np.arange(len(s)) // 4) % 8 == 0]
+        x0 = x0[x0[:, 2] > x0[:, 1]]
+        m = x0[:, 2] - x0[:, 1]
+        assert m[:32].mean() > m[-32:].mean()
+        assert per_xcd * 8 == len(s)
+    if nr * nphi <= 512 * 1536:
+        assert len(t) == 0 and len(s) == 0
