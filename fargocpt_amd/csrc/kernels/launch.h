@@ -269,7 +269,7 @@ std::vector<int> source_schedule(const Dev &P)
 }
 // Chunks of graded length for k_transport_fused, in dispatch order: (first ring, one past the last) pairs.
 //
-// Why: the wavefront trace of the kernel (profiles/tools/wave_trace_transport.py, profiles/r03_tf_wave_trace.txt) shows
+// Why: the wavefront trace of the kernel (profiles/tools/wave_trace_transport.py, profiles/r03_tf_wave_trace_uniform.txt) shows
 // equal chunks leaving a long tail.  At 2048 x 4096 the 8 034 wavefronts of 103 twenty-ring chunks take two rounds of
 // the 4 096 slots; a SIMD issues for its OLDEST wavefront first, so the four wavefronts of a SIMD finish 58 ... 95 us
 // after a common start, the second round starts staggered over 40 us and ends staggered over 58 us, during which the
