@@ -264,8 +264,16 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
         const cdptr tn = (cdptr)(const void *)(P.theta_tab + (m + 1 >= 0 && m + 1 < nr ? m + 1 : 0));
         const double r_next = tn[offsetof(ThetaRow, rmed) / sizeof(double)], romega_next = tn[offsetof(ThetaRow, r_omega) / sizeof(double)];
         // ---- R: slopes of ring m-1, fluxes through interface k = m-1 --------------------------
+        // (the first iterations of a chunk only fill the window: the first slope that reaches a result is that of ring
+        //  r0-2 -- as hs1 of the flux through interface r0-1 -- formed at m = r0-1 from the differences of rings r0-3 ..
+        //  r0-1; the kernels that carry the previous difference instead of re-forming it need it from m = r0-2)
         double F0[NQ][C];
-        {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                F0[q][c] = 0.0;
+        if (m >= r0 - (DIET ? 1 : 2)) {
             const double idr_m = rk.idr_up;          // 1 / (Rmed[m] - Rmed[m-1]) when both rings exist
             const bool lim_ok = k > 0 && k < nr - 1; // boundary rings carry no slope (:360-372)
             const bool open = k > 0 && k < nr;       // interface carries a flux
