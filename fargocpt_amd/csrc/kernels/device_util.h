@@ -215,3 +215,7 @@ __device__ __forceinline__ void st_off(double *base, unsigned off, double v) { *
 __device__ __forceinline__ D2 ld2_off(const double *base, unsigned off) { return LD2((const double *)((const char *)base + off)); }
 __device__ __forceinline__ void st2_off(double *base, unsigned off, D2 v) { ST2((double *)((char *)base + off), v); }
 
+
+// wavefronts per workgroup of the marching kernels: always launched with 256 threads (a constant instead of
+// blockDim.x, which is a load from the dispatch packet and a wait at the top of every wavefront)
+#define MARCH_WAVES 4

@@ -101,13 +101,13 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
     const int nr = P.nr, nphi = P.nphi;
     int wave, seg, k0, k1;
     if (P.sm_sched) { // (segment, first ring, one past the last) of every wavefront in the order of dispatch: source_schedule()
-        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6));
         const int __attribute__((address_space(4))) *e = (const int __attribute__((address_space(4))) *)P.sm_sched + 4 * wave;
         seg = e[0], k0 = e[1], k1 = e[2];
         if (k0 >= k1)
             return;
     } else {
-        wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * MARCH_WAVES + (threadIdx.x >> 6));
         const int chunk = wave / segs;
         seg = wave - chunk * segs;
         k0 = chunk * rows_per_chunk;
@@ -152,14 +152,15 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
         S_m = ld_off(P.sigma, MOFF(r));
         F_m = ld_off(fgrid, MOFF(r));
         va0_m = ld_off(P.vazi, MOFF(r));
-        Sp_m = PREV(S_m);
-        va0n_m = NEXT(va0_m);
     }
-    // software prefetch of the next input ring
+    // software prefetch of the next input ring (requested before the first ring is used: one round trip, not two)
     int rn = k0 - 2;
     double pS = ld_off(P.sigma, MOFF(crow(rn))), pF = ld_off(fgrid, MOFF(crow(rn)));
     double pG = ACC ? ld_off(P.accel_az, MOFF(crow(rn))) : 0.0;
     double pVa = ld_off(P.vazi, MOFF(crow(rn))), pVr = ld_off(P.vrad, MOFF(vrow(rn)));
+    asm volatile("" : "+v"(S_m), "+v"(va0_m), "+v"(pVr)); // (keeps the lane shifts below, and their wait, behind the last request)
+    Sp_m = PREV(S_m);
+    va0n_m = NEXT(va0_m);
 
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
         const SrcRow R = crow_load(P.src_tab, m + 2); // every per-ring factor of this iteration, one batch
@@ -381,13 +382,13 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
     const int nr = P.nr, nphi = P.nphi;
     int wave, seg, k0, k1;
     if (P.sm_sched) { // (segment, first ring, one past the last) of every wavefront in the order of dispatch: source_schedule()
-        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6));
         const int __attribute__((address_space(4))) *e = (const int __attribute__((address_space(4))) *)P.sm_sched + 4 * wave;
         seg = e[0], k0 = e[1], k1 = e[2];
         if (k0 >= k1)
             return;
     } else {
-        wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        wave = __builtin_amdgcn_readfirstlane(xcd_block(blockIdx.x, gridDim.x) * MARCH_WAVES + (threadIdx.x >> 6));
         const int chunk = wave / segs;
         seg = wave - chunk * segs;
         k0 = chunk * rows_per_chunk;
@@ -475,15 +476,18 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
         S_m = ADI_LD(P.sigma, r);
         va0_m = ADI_LD(P.vazi, r);
         e0_m = ADI_LD(P.energy, r);
-        F_m = POT ? potential_of(r, S_m, e0_m) : ADI_LD(fgrid, r);
-        Sp_m = PREV(S_m);
-        va0n_m = NEXT(va0_m);
+        if (!POT)
+            F_m = ADI_LD(fgrid, r);
     }
-    // software prefetch of the next input ring
+    // software prefetch of the next input ring (requested before the first ring is used: one round trip, not two)
     int rn = k0 - 2;
     double pS = ADI_LD(P.sigma, crow(rn)), pF = POT ? 0.0 : ADI_LD(fgrid, crow(rn)), pE = ADI_LD(P.energy, crow(rn));
     double pG = ACC ? ADI_LD(P.accel_az, crow(rn)) : 0.0;
     double pVa = ADI_LD(P.vazi, crow(rn)), pVr = ADI_LD(P.vrad, vrow(rn));
+    if (POT)
+        F_m = potential_of(crow(k0 - 3), S_m, e0_m);
+    Sp_m = PREV(S_m);
+    va0n_m = NEXT(va0_m);
 
     for (int m = k0 - 2; m <= k1 + 1; ++m) {
         const SrcRow R = crow_load(P.src_tab, m + 2); // every per-ring factor of this iteration, one batch

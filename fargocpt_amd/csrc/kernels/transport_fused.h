@@ -98,12 +98,12 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     }
     int chunk_l, wave;
     if (ch.count >= TF_XCD_CHUNKS) {
-        const int xcd = blockIdx.x & 7, wq = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const int xcd = blockIdx.x & 7, wq = (blockIdx.x >> 3) * MARCH_WAVES + (threadIdx.x >> 6);
         const int zq = __builtin_amdgcn_readfirstlane(wq / tiles);
         chunk_l = xcd + 8 * zq; // chunk within this launch
         wave = __builtin_amdgcn_readfirstlane(chunk_l * tiles + (wq - zq * tiles));
     } else {
-        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6));
         chunk_l = wave / tiles;
     }
     if (chunk_l >= ch.count)
@@ -236,17 +236,19 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     // issued, and only then the iteration's stores.  The one s_waitcnt vmcnt(0) per iteration then
     // meets operations that are a whole compute phase old (vmcnt counts stores too; waiting right
     // behind them costs a round trip per ring at 2-3 waves per SIMD).
+    // (the three rings that start a chunk are requested together: one memory round trip before the loop, not two)
     RingRaw nxt;
-    fetch(r0 - 4, nxt);
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-        vr_last[c] = nxt.vr[c]; // v_r(r0-3)
-    fetch(r0 - 3, nxt);
     {
+        RingRaw first, second;
+        fetch(r0 - 4, first);
+        fetch(r0 - 3, second);
+        fetch(r0 - 2, nxt);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            vr_last[c] = first.vr[c]; // v_r(r0-3)
         const ThetaRow t3 = crow_load(P.theta_tab, r0 - 3 >= 0 ? r0 - 3 : 0);
-        convert(r0 - 3, nxt, t3.rmed, t3.r_omega);
+        convert(r0 - 3, second, t3.rmed, t3.r_omega);
     }
-    fetch(r0 - 2, nxt);
     int ns_prev = 0;
 
     for (int m = r0 - 3; m <= r1 + 1; ++m) {
