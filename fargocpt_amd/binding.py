@@ -192,12 +192,12 @@ class Library:
         return out
 
     def selftest_chunk_tables(self, nr: int, nphi: int, n_cu: int = 256, adiabatic: bool = False, damp_inner: int = 0, damp_outer: int = 0):
-        """(transport chunks [n, 2], source wavefronts [m, 3]) the library would use for such a slab and device: host logic, no GPU."""
+        """(transport wavefronts [n, 3], source wavefronts [m, 3]) the library would use for such a slab and device: host logic, no GPU."""
         nt, ns = _i32(), _i32()
         f = self.fn("selftest_chunk_tables")
         args = (_i32(nr), _i32(nphi), _i32(n_cu), _i32(int(adiabatic)), _i32(damp_inner), _i32(damp_outer))
         self.check(f(*args, None, _i32(0), C.byref(nt), None, _i32(0), C.byref(ns)), "selftest_chunk_tables")
-        t, s = np.zeros((nt.value, 2), dtype=np.int32), np.zeros((ns.value, 3), dtype=np.int32)
+        t, s = np.zeros((nt.value, 3), dtype=np.int32), np.zeros((ns.value, 3), dtype=np.int32)
         self.check(f(*args, t.ctypes.data_as(C.POINTER(_i32)), _i32(nt.value), C.byref(nt),
                      s.ctypes.data_as(C.POINTER(_i32)), _i32(ns.value), C.byref(ns)), "selftest_chunk_tables")
         return t, s
@@ -273,10 +273,10 @@ class Context:
         self._call("set_transport_chunks", a.ctypes.data_as(C.POINTER(_i32)), _i32(a.size))
 
     def transport_chunks(self) -> np.ndarray:
-        """(first ring, one past the last) of every chunk of the fused transport kernel, dispatch order; empty: equal chunks."""
+        """(tile, first ring, one past the last) of every wavefront of the fused transport kernel, dispatch order; empty: equal chunks."""
         n = _i32()
         self._call("transport_chunks", None, _i32(0), C.byref(n))
-        out = np.zeros((n.value, 2), dtype=np.int32)
+        out = np.zeros((n.value, 3), dtype=np.int32)
         if n.value:
             self._call("transport_chunks", out.ctypes.data_as(C.POINTER(_i32)), _i32(n.value), C.byref(n))
         return out

@@ -61,7 +61,7 @@ void options_from_environment(Options &o)
     o.transport_fused = o.transport_rows = o.source_rows = o.theta_rows = -1;
     o.transport_graded = 1;
     o.source_graded = -1;
-    o.transport_big = o.transport_ladder = -1;
+    o.transport_big = o.transport_ladder = o.transport_rank_grade = -1;
     o.transport_fallback = o.transport_split = o.fused_source = o.march_source = o.march_source_adi = 1;
     o.theta_march = o.theta_fused = o.cfl_rings = o.cfl_split = o.source_ring_parts = o.fused_damping = 1;
     o.cfl_wide_blocks = -1;
@@ -194,10 +194,10 @@ void apply_options(fcpt_ctx *c, bool at_create = true)
             slow = c->ring_ref_damped;
         const std::vector<int> sched = transport_schedule(c->P, slow, &c->tf_lengths);
         c->tf_sched_host.clear();
-        if (!sched.empty() && sched.size() <= (size_t)2 * (c->P.nr + 8) &&
+        if (!sched.empty() && sched.size() <= c->tf_sched_cap &&
             hipMemcpy(c->tf_sched_dev, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
             c->P.tf_sched = c->tf_sched_dev;
-            c->P.tf_sched_n = (int)(sched.size() / 2);
+            c->P.tf_sched_n = (int)(sched.size() / 4);
             c->tf_sched_host = sched;
         }
     }
@@ -687,7 +687,8 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
         c->ring_ref_damped.assign(nr, 0);
         for (int i = 0; i < nr; ++i)
             c->ring_ref_damped[i] = (ty[0][i] == 1 || ty[1][i] == 1 || ty[2][i] == 1 || ty[3][i] == 1) ? 1 : 0;
-        if (!rc) rc = dev_alloc(c, &c->tf_sched_dev, (size_t)2 * (nr + 8));
+        c->tf_sched_cap = (size_t)4 * 65536; // graded chunks: two to three rounds of a 512-CU device's wavefront slots, and the padding
+        if (!rc) rc = dev_alloc(c, &c->tf_sched_dev, c->tf_sched_cap);
         c->sm_sched_cap = (size_t)4 * (8 * 4 * 8 * 64 + 64); // one entry per wavefront slot of a 512-CU device at 8 per SIMD
         if (!rc) rc = dev_alloc(c, &c->sm_sched_dev, c->sm_sched_cap);
         if (const char *q = getenv("FCPT_TF_SCHEDULE")) { // tuning runs: "28x56,12x24,6" = 56 chunks of 28 rings, 24 of 12, the rest of 6
@@ -814,16 +815,15 @@ int fcpt_set_transport_chunks(fcpt_ctx *c, const int32_t *lengths, int32_t n)
     return FCPT_OK;
 }
 
-int fcpt_transport_chunks(const fcpt_ctx *c, int32_t *first_last, int32_t capacity, int32_t *n_chunks)
+int fcpt_transport_chunks(const fcpt_ctx *c, int32_t *tile_first_last, int32_t capacity, int32_t *n_wavefronts)
 {
-    if (!c || !n_chunks || capacity < 0 || (capacity > 0 && !first_last))
+    if (!c || !n_wavefronts || capacity < 0 || (capacity > 0 && !tile_first_last))
         return FCPT_EINVAL;
-    const int n = (int)(c->tf_sched_host.size() / 2);
-    *n_chunks = n;
-    for (int k = 0; k < n && k < capacity; ++k) {
-        first_last[2 * k] = c->tf_sched_host[2 * k];
-        first_last[2 * k + 1] = c->tf_sched_host[2 * k + 1];
-    }
+    const int n = (int)(c->tf_sched_host.size() / 4);
+    *n_wavefronts = n;
+    for (int k = 0; k < n && k < capacity; ++k)
+        for (int q = 0; q < 3; ++q)
+            tile_first_last[3 * k + q] = c->tf_sched_host[4 * k + q];
     return FCPT_OK;
 }
 
@@ -1205,10 +1205,11 @@ int fcpt_selftest_chunk_tables(int32_t nr, int32_t nphi, int32_t n_cu, int32_t a
     options_from_environment(opt);
     std::vector<int> t, s;
     selftest_chunk_tables(nr, nphi, n_cu, adiabatic != 0, damp_inner, damp_outer, opt, t, s);
-    *n_transport = (int32_t)(t.size() / 2);
+    *n_transport = (int32_t)(t.size() / 4);
     *n_source = (int32_t)(s.size() / 4);
     for (int k = 0; k < *n_transport && k < transport_capacity; ++k)
-        transport_first_last[2 * k] = t[2 * k], transport_first_last[2 * k + 1] = t[2 * k + 1];
+        for (int q = 0; q < 3; ++q)
+            transport_first_last[3 * k + q] = t[4 * k + q];
     for (int k = 0; k < *n_source && k < source_capacity; ++k)
         for (int q = 0; q < 3; ++q)
             source_seg_first_last[3 * k + q] = s[4 * k + q];

@@ -67,7 +67,8 @@ struct fcpt_ctx {
     int *sm_sched_dev = nullptr;      // storage of Dev::sm_sched
     size_t sm_sched_cap = 0;          // ... in ints
     std::vector<int> sm_sched_host;
-    int *tf_sched_dev = nullptr;      // storage of Dev::tf_sched (2 (nr + 8) ints)
+    int *tf_sched_dev = nullptr;      // storage of Dev::tf_sched
+    size_t tf_sched_cap = 0;          // ... in ints
     std::vector<int> tf_lengths;      // explicit chunk lengths in dispatch order (fcpt_set_transport_chunks; FCPT_TF_SCHEDULE at fcpt_create); empty: built-in
     std::vector<int> tf_sched_host;   // what Dev::tf_sched holds
     bool damp_foldable = false; // ... and its damping can be folded into the transport (no "mean" target, Euler)

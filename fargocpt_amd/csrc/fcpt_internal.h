@@ -137,6 +137,7 @@ struct Options {
     int transport_rows;     // rings per marching chunk of k_transport_fused (> 0: equal chunks of that many rings)
     int transport_graded;   // 1: chunks of graded length, long ones first (transport_schedule()); 0: equal chunks
     int transport_big;      // graded: rings per chunk of the first round (-1: from the grid and the wavefront slots)
+    int transport_rank_grade; // one round of wavefronts: per cent by which the chunks of the last rank of a SIMD are shorter than those of the first (transport_rank_table(); 0: equal chunks, -1: built-in)
     int transport_ladder;   // graded: per cent of the previous length each further round of chunks gets (-1: built-in)
     int source_rows;        // ... of k_source_march(_adi) (> 0: equal chunks of that many rings)
     int source_graded;      // per cent by which the wavefronts a SIMD receives last get shorter chunks than those it receives first (source_schedule(); 0: equal chunks, -1: built-in)
@@ -163,7 +164,7 @@ struct Options {
     int profile_stride;     // fcpt_profile_start: every n-th launch of the selected kernels is timed (an event pair costs ~3 us of stream time)
 };
 #define FCPT_OPTION_NAMES                                                                                        \
-    X(transport_fused) X(transport_rows) X(transport_graded) X(transport_big) X(transport_ladder) X(source_rows) X(source_graded) X(theta_rows) X(transport_fallback) X(transport_split)    \
+    X(transport_fused) X(transport_rows) X(transport_graded) X(transport_big) X(transport_ladder) X(transport_rank_grade) X(source_rows) X(source_graded) X(theta_rows) X(transport_fallback) X(transport_split)    \
     X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_wide_blocks) X(cfl_split)   \
     X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(bc_in_cfl) X(comm_overlap) X(comm_loopback) X(graph_steps) X(profile_stride)
 
@@ -218,7 +219,7 @@ struct Dev {
     const DampRow *damp_tab;
     const int *sm_sched;    // wavefronts of the marching source kernels in dispatch order: (segment, first ring, one past the last, 0)
     int sm_sched_n;         // ... how many, a multiple of 4 (0: equal chunks of source_rows() rings)
-    const int *tf_sched;    // chunks of k_transport_fused in dispatch order: (first ring, one past the last) pairs
+    const int *tf_sched;    // wavefronts of k_transport_fused in dispatch order: (tile, first ring, one past the last, 0)
     int tf_sched_n;         // ... how many (0: equal chunks of transport_rows() rings)
     int *shift_jump;        // set by k_transport_fused when |Nshift[i]-Nshift[i-1]| > 1 somewhere: the unfused kernels take over
     // wave damping folded into the end of the transport step: per-ring factor f = ((r-r_lim)/(r_edge-r_lim))^2

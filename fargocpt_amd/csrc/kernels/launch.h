@@ -282,7 +282,7 @@ std::vector<int> source_schedule(const Dev &P)
 // count 1.4 rings each).  Returns an empty vector where equal chunks stay: tuning runs (transport_rows > 0,
 // transport_graded = 0) and grids whose wavefronts fit the slots once (the shortest chunks win there: transport_rows()).
 static int transport_rows(const Dev &P);
-std::vector<int> transport_schedule(const Dev &P, const std::vector<int> &slow, const std::vector<int> *lengths)
+static std::vector<int> transport_chunk_list(const Dev &P, const std::vector<int> &slow, const std::vector<int> *lengths)
 {
     std::vector<int> out;
     if (P.nphi < 256 || P.opt.transport_rows > 0 || P.opt.transport_graded == 0)
@@ -347,6 +347,115 @@ std::vector<int> transport_schedule(const Dev &P, const std::vector<int> &slow, 
             out.push_back(hi), out.push_back(r1);
         }
     }
+    return out;
+}
+// One round of wavefronts (grids whose equal chunks fit the slots once): chunk lengths matched to the SIMD rank of the
+// wavefront, exactly as source_schedule() does for the source marches -- the trace of the 1024 x 3072 transport
+// (profiles/r03_tf_wave_trace_config3_uniform.txt) shows all 3 712 wavefronts resident for 50 us and then leaving over
+// the next 43.  Entries (tile, first ring, one past the last, 0) indexed by blockIdx.x * 4 + wavefront of the workgroup.
+static std::vector<int> transport_rank_table(const Dev &P, const std::vector<int> &slow)
+{
+    std::vector<int> out;
+    if (P.opt.transport_rank_grade == 0)
+        return out;
+    const int tstride = 64 - (TfHalo<1>::lo + TfHalo<1>::hi);
+    const int tiles = (P.nphi + tstride - 1) / tstride;
+    const int occ = 4, PRE = 5;
+    const int wpr = device_cus() / 8 * 4; // wavefronts of one rank in an XCD: one per SIMD
+    const int rows = P.nr;
+    if (wpr < 4 || rows < 128)
+        return out;
+    const int cpc = wpr * occ / tiles; // chunks per tile column in an XCD's eighth of the rings
+    const int rx = rows / 8;
+    if (cpc < 2 || rx / cpc < 10)
+        return out; // short chunks (the grid does not fill the slots with chunks of ten rings): transport_rows()'s equal ones
+    if ((rx + cpc) / cpc > 64)
+        return out;
+    const double g = (P.opt.transport_rank_grade > 0 && P.opt.transport_rank_grade < 100 ? P.opt.transport_rank_grade : (P.adiabatic ? 45 : 60)) * 0.01;
+    double w[4];
+    for (int r = 0; r < occ; ++r)
+        w[r] = 1.0 - g * r / (occ - 1);
+    // cost of the rings: a damping-zone ring (reference values loaded and waited for) counts 1.4 -- the XCDs get equal
+    // cost, not equal numbers of rings (the zones sit in the first and the last XCD's range), and so do the chunks
+    std::vector<double> cum(rows + 1, 0.0);
+    for (int i = 0; i < rows; ++i)
+        cum[i + 1] = cum[i] + ((i < (int)slow.size() && slow[i]) ? 1.4 : 1.0);
+    auto ring_at = [&](double cost) { // first ring index whose cumulated cost reaches `cost`
+        int lo = 0, hi = rows;
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            if (cum[mid] < cost)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    const int nblk = (cpc * tiles + 3) / 4;
+    out.assign((size_t)nblk * 8 * 4 * 4, 0);
+    for (int x = 0; x < 8; ++x) {
+        const int A = x == 0 ? 0 : ring_at(cum[rows] * x / 8.0), B = x == 7 ? rows : ring_at(cum[rows] * (x + 1) / 8.0);
+        const double n = cum[B] - cum[A];
+        for (int c = 0; c < tiles; ++c) {
+            double sw = 0.0;
+            for (int j = 0; j < cpc; ++j) {
+                const int q = j * tiles + ((j & 1) ? tiles - 1 - c : c);
+                sw += w[q / wpr < occ ? q / wpr : occ - 1];
+            }
+            const double scale = (n + (double)cpc * PRE) / sw;
+            double edge = 0.0;
+            int k0 = A;
+            for (int j = 0; j < cpc; ++j) {
+                const int q = j * tiles + ((j & 1) ? tiles - 1 - c : c);
+                edge += scale * w[q / wpr < occ ? q / wpr : occ - 1] - PRE;
+                const int k1 = j == cpc - 1 ? B : ring_at(cum[A] + edge);
+                if (k1 < k0 + 2 || k1 > B) {
+                    out.clear();
+                    return out;
+                }
+                const size_t t = ((size_t)(q / 4) * 8 + x) * 4 + (q & 3);
+                out[4 * t] = c, out[4 * t + 1] = k0, out[4 * t + 2] = k1;
+                k0 = k1;
+            }
+        }
+    }
+    return out;
+}
+// The table k_transport_fused runs from: per wavefront (tile, first ring, one past the last, 0) in the order of
+// dispatch -- graded chunks (several rounds of wavefronts: transport_chunk_list, every chunk's tiles side by side on one
+// XCD), rank-matched chunks (one round: transport_rank_table), or empty: equal chunks of transport_rows() rings.
+std::vector<int> transport_schedule(const Dev &P, const std::vector<int> &slow, const std::vector<int> *lengths)
+{
+    std::vector<int> out;
+    if (P.nphi < 256 || P.opt.transport_rows > 0 || P.opt.transport_fused == 0 || P.opt.transport_fused == 2)
+        return out;
+    const std::vector<int> chunks = transport_chunk_list(P, slow, lengths);
+    if (chunks.empty()) {
+        const bool explicit_spec = lengths && !lengths->empty();
+        if (explicit_spec || P.opt.transport_graded == 0)
+            return out;
+        // one round of equal chunks?
+        const int tstride = 64 - (TfHalo<1>::lo + TfHalo<1>::hi);
+        const long tiles = (P.nphi + tstride - 1) / tstride;
+        const int rows_u = transport_rows(P);
+        if ((long)((P.nr + rows_u - 1) / rows_u) * tiles > (long)device_cus() * 4 * 4)
+            return out;
+        return transport_rank_table(P, slow);
+    }
+    const int tstride = 64 - (TfHalo<1>::lo + TfHalo<1>::hi);
+    const int tiles = (P.nphi + tstride - 1) / tstride;
+    const int count = (int)(chunks.size() / 2);
+    // as the kernel deals equal chunks: workgroup b runs on XCD b % 8; chunk c on XCD c % 8, its tiles side by side
+    const int nblk = 8 * ((((count + 7) / 8) * tiles + 3) / 4);
+    out.assign((size_t)nblk * 4 * 4, 0);
+    for (int b = 0; b < nblk; ++b)
+        for (int wv = 0; wv < 4; ++wv) {
+            const int xcd = b & 7, wq = (b >> 3) * 4 + wv, zq = wq / tiles, c = xcd + 8 * zq;
+            if (c >= count)
+                continue;
+            const size_t t = (size_t)b * 4 + wv;
+            out[4 * t] = wq - zq * tiles, out[4 * t + 1] = chunks[2 * c], out[4 * t + 2] = chunks[2 * c + 1];
+        }
     return out;
 }
 // test hook (no GPU needed): the two tables for a grid, an EOS and a device of n_cu compute units; the first
@@ -701,7 +810,8 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         // for flows known to be benign; a violation is then reported as FCPT_ESHEAR.
         const int fallback = P.opt.transport_fallback != 0;
         TfChunks ch = {chunks, chunks, 0, 1, nullptr};
-        if (part == TRANSPORT_ALL && P.tf_sched_n > 0 && P.opt.transport_rows <= 0 && CF == 1)
+        const bool sched = part == TRANSPORT_ALL && P.tf_sched_n > 0 && P.opt.transport_rows <= 0 && CF == 1;
+        if (sched)
             ch = TfChunks{P.tf_sched_n, P.tf_sched_n, 0, 1, P.tf_sched};
         const int c_lo = (P.nr - 2 * FCPT_OVERLAP) / rows;    // first chunk of the outer tail (holds row nr - 14)
         const int lead = (2 * FCPT_OVERLAP + rows - 1) / rows; // chunks that hold rows [0, 14)
@@ -711,7 +821,9 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
             ch = TfChunks{c_lo - lead, 0, lead, 0, nullptr};
         res.split = part != TRANSPORT_ALL;
         // (8 XCDs x the wavefronts of ceil(count / 8) chunks, four to a workgroup: see the chunk mapping in the kernel)
-        const dim3 grid(ch.count >= TF_XCD_CHUNKS ? 8 * ((((ch.count + 7) / 8) * tiles + 3) / 4) : (ch.count * tiles + 3) / 4), block(256);
+        const dim3 grid(sched ? (ch.count + 3) / 4
+                              : (ch.count >= TF_XCD_CHUNKS ? 8 * ((((ch.count + 7) / 8) * tiles + 3) / 4) : (ch.count * tiles + 3) / 4)),
+            block(256);
 #define TFK2(ID, KK, CC, AA, DD)                                                                    \
     if (P.limiter == FCPT_LIMITER_MC)                                                                \
         KLAUNCH(ID, (KK<CC, AA, DD, FCPT_LIMITER_MC>), grid, block, P, Wm, tiles, rows, fallback, ch); \

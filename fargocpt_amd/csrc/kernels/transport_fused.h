@@ -27,8 +27,8 @@
 // `skip` chunks further up.  All chunks at once: {n, n, 0, 1}.  Slabs with neighbours march the chunks that hold
 // the rings the neighbours are waiting for first (fcpt_step_device_begin): {1 + tail, 1, gap, 1} then {gap, 0, 1, 0}.
 #define TF_XCD_CHUNKS 16 /* launches of at least this many chunks deal whole chunks to the XCDs */
-// sched != null: chunk c of the launch is rings [sched[2c], sched[2c+1]) -- graded lengths, long chunks first
-// (transport_schedule() in launch.h); the table is in dispatch order, so lead / skip do not apply.
+// sched != null: wavefront w of the launch (blockIdx.x * 4 + its index in the workgroup) marches tile sched[4w] over rings
+// [sched[4w+1], sched[4w+2]) -- transport_schedule() in launch.h; count = entries, lead / skip do not apply.
 struct TfChunks {
     int count, lead, skip, advance_clock;
     const int *sched;
@@ -96,36 +96,45 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
         }
         return;
     }
-    int chunk_l, wave;
-    if (ch.count >= TF_XCD_CHUNKS) {
-        const int xcd = blockIdx.x & 7, wq = (blockIdx.x >> 3) * MARCH_WAVES + (threadIdx.x >> 6);
-        const int zq = __builtin_amdgcn_readfirstlane(wq / tiles);
-        chunk_l = xcd + 8 * zq; // chunk within this launch
-        wave = __builtin_amdgcn_readfirstlane(chunk_l * tiles + (wq - zq * tiles));
-    } else {
-        wave = __builtin_amdgcn_readfirstlane(blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6));
-        chunk_l = wave / tiles;
-    }
-    if (chunk_l >= ch.count)
-        return;
-    int chunk = chunk_l < ch.lead ? chunk_l : chunk_l + ch.skip;
-    if (ch.lead == ch.count && ch.skip == 0) // all chunks in one launch: 0, n-1, 1, n-2, ...
-        chunk = (chunk_l & 1) ? ch.count - 1 - (chunk_l >> 1) : (chunk_l >> 1);
     const int nr = P.nr, nphi = P.nphi;
-    int r0 = chunk * rows, r1 = r0 + rows < nr ? r0 + rows : nr;
-    if (ch.sched) {
-        const int __attribute__((address_space(4))) *tab = (const int __attribute__((address_space(4))) *)ch.sched;
-        chunk = chunk_l;
-        r0 = tab[2 * chunk_l], r1 = tab[2 * chunk_l + 1];
+    int tile, r0, r1, trace_slot;
+    if (ch.sched) { // (tile, first ring, one past the last) of every wavefront in the order of dispatch: transport_schedule()
+        const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6));
+        if (wave >= ch.count)
+            return;
+        const int __attribute__((address_space(4))) *e = (const int __attribute__((address_space(4))) *)ch.sched + 4 * wave;
+        tile = e[0], r0 = e[1], r1 = e[2];
+        trace_slot = wave;
+        if (r0 >= r1)
+            return;
+    } else {
+        int chunk_l, wave;
+        if (ch.count >= TF_XCD_CHUNKS) {
+            const int xcd = blockIdx.x & 7, wq = (blockIdx.x >> 3) * MARCH_WAVES + (threadIdx.x >> 6);
+            const int zq = __builtin_amdgcn_readfirstlane(wq / tiles);
+            chunk_l = xcd + 8 * zq; // chunk within this launch
+            wave = __builtin_amdgcn_readfirstlane(chunk_l * tiles + (wq - zq * tiles));
+        } else {
+            wave = __builtin_amdgcn_readfirstlane(blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6));
+            chunk_l = wave / tiles;
+        }
+        if (chunk_l >= ch.count)
+            return;
+        int chunk = chunk_l < ch.lead ? chunk_l : chunk_l + ch.skip;
+        if (ch.lead == ch.count && ch.skip == 0) // all chunks in one launch: 0, n-1, 1, n-2, ...
+            chunk = (chunk_l & 1) ? ch.count - 1 - (chunk_l >> 1) : (chunk_l >> 1);
+        r0 = chunk * rows, r1 = r0 + rows < nr ? r0 + rows : nr;
+        if (r0 >= nr)
+            return;
+        tile = wave - chunk_l * tiles;
+        trace_slot = chunk * tiles + tile;
     }
-    if (r0 >= nr)
-        return;
-    const int tile = wave - chunk_l * tiles;
-#ifdef TF_TRACE /* profiles/tools/wave_trace_transport.py: start and end of every wavefront, 10 ns ticks, in the (isothermal: unused) temperature grid */
+    (void)trace_slot;
+#ifdef TF_TRACE /* profiles/tools/wave_trace_transport.py: start and end of every wavefront, 10 ns ticks, in the temperature grid (which no marching kernel touches) */
     if (lane == 0) {
-        W.temperature[4 * (chunk * tiles + tile)] = (double)wall_clock64();
-        W.temperature[4 * (chunk * tiles + tile) + 2] = (double)r0;
-        W.temperature[4 * (chunk * tiles + tile) + 3] = (double)r1;
+        W.temperature[4 * trace_slot] = (double)wall_clock64();
+        W.temperature[4 * trace_slot + 2] = (double)r0;
+        W.temperature[4 * trace_slot + 3] = (double)r1;
     }
 #endif
     const int stride = 64 * C - (LO + HI);
@@ -487,7 +496,7 @@ __device__ __forceinline__ void transport_fused_body(const Dev &P, const Dev &W,
     }
 #ifdef TF_TRACE
     if (lane == 0)
-        W.temperature[4 * (chunk * tiles + tile) + 1] = (double)wall_clock64();
+        W.temperature[4 * trace_slot + 1] = (double)wall_clock64();
 #endif
 }
 

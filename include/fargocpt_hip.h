@@ -310,7 +310,7 @@ int fcpt_synchronize(fcpt_ctx *ctx);
 /* Kernel-selection switches of one context, by name (lower case, e.g. "transport_fallback"): which of the
  * parity-tested kernel variants the step uses, marching-chunk lengths, overlap of the ghost exchange.  The
  * environment variables FCPT_<NAME> only provide the defaults read once in fcpt_create; no launch reads the
- * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows, transport_graded, transport_big, transport_ladder, source_graded,
+ * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows, transport_graded, transport_big, transport_ladder, transport_rank_grade, source_graded,
  * source_rows, theta_rows, transport_fallback, transport_split, fused_source, march_source, march_source_adi,
  * theta_march, theta_fused, cfl_rings, cfl_wide_blocks, cfl_split, source_ring_parts, fused_damping, inline_potential, cfl_thermal, bc_fold, bc_in_cfl, comm_overlap,
  * comm_loopback, graph_steps, profile_stride (fcpt_profile_start times every n-th launch of the selected kernels).
@@ -323,15 +323,18 @@ int fcpt_set_option(fcpt_ctx *ctx, const char *name, int32_t value);
 int fcpt_get_option(const fcpt_ctx *ctx, const char *name, int32_t *value);
 
 /* The chunks of rings into which the fused Transport() kernel (src/TransportEuler.cpp:112-136 as one marching pass)
- * divides the slab, in the order they are dispatched: the library grades their lengths (long chunks first, options
- * transport_graded / transport_big / transport_ladder) so that the GPU's wavefront slots run dry together.  The
- * chunking never changes a result -- every ring is computed by exactly one chunk from the same operands.
- * fcpt_transport_chunks reports the table in use as (first ring, one past the last ring) pairs (n_chunks = 0: equal
- * chunks of transport_rows rings); fcpt_set_transport_chunks replaces the lengths by an explicit list, the last entry
- * repeating to the end of the slab (n = 0: back to the built-in grading) -- a tuning and test hook, like the options.
+ * divides the slab: one wavefront marches one tile of 53 cells over one chunk.  Where the slab needs several rounds of
+ * the GPU's wavefront slots the library grades the chunk lengths (long chunks first: options transport_graded,
+ * transport_big, transport_ladder), where one round covers it the lengths follow the rate at which a SIMD serves its
+ * wavefronts (transport_rank_grade), so that the slots run dry together.  The chunking never changes a result -- every
+ * ring of a tile is computed by exactly one wavefront from the same operands.
+ * fcpt_transport_chunks reports (tile, first ring, one past the last ring) per wavefront in the order of dispatch, entries
+ * with first == last being idle (n_wavefronts = 0: equal chunks of transport_rows rings); fcpt_set_transport_chunks
+ * replaces the lengths by an explicit list of chunk lengths, dealt from both ends of the slab, the last entry repeating
+ * (n = 0: back to the built-in choice) -- a tuning and test hook, like the options.
  * (No counterpart in the reference: its loops are not chunked.) */
 int fcpt_set_transport_chunks(fcpt_ctx *ctx, const int32_t *lengths, int32_t n);
-int fcpt_transport_chunks(const fcpt_ctx *ctx, int32_t *first_last, int32_t capacity, int32_t *n_chunks);
+int fcpt_transport_chunks(const fcpt_ctx *ctx, int32_t *tile_first_last, int32_t capacity, int32_t *n_wavefronts);
 /* Likewise the marching kernels of the source step (update_with_sourceterms ... SubStep3 as one pass, src/SourceEuler.cpp,
  * src/viscosity/): where one round of wavefronts covers the slab, every wavefront's chunk length is matched to the rate at
  * which its SIMD will serve it (option source_graded, per cent of difference between first and last rank; 0: equal
@@ -549,7 +552,7 @@ int fcpt_profile_stop(fcpt_ctx *ctx, double *ms_total, int64_t *launches);
  * cells on a device of n_cu compute units (8 XCDs), isothermal or ideal EOS, with damping zones of damp_inner / damp_outer
  * rings folded into the transport.  n_transport / n_source = 0: equal chunks (small grids, rings of > 8192 cells ...). */
 int fcpt_selftest_chunk_tables(int32_t nr, int32_t nphi, int32_t n_cu, int32_t adiabatic, int32_t damp_inner, int32_t damp_outer,
-                               int32_t *transport_first_last, int32_t transport_capacity, int32_t *n_transport,
+                               int32_t *transport_tile_first_last, int32_t transport_capacity, int32_t *n_transport,
                                int32_t *source_seg_first_last, int32_t source_capacity, int32_t *n_source);
 /* Test hook: out[k] = 0.5 * flux_limiter(a[k], b[k]) (src/TransportEuler.cpp:306-337; limiter = FCPT_LIMITER_*) exactly
  * as the transport kernels evaluate it on the device -- the van Leer form there is branch-free (max(ab, 0) times a

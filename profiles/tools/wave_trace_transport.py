@@ -3,25 +3,28 @@
 ticks of s_memrealtime, in the temperature grid): which chunks are slow, and where the idle wavefront slots come from.
 
     make -C fargocpt_amd/csrc alt ALTNAME=tftrace EXTRA=-DTF_TRACE
-    FCPT_LIB_PATH=$PWD/fargocpt_amd/libfargocpt_hip_tftrace.so python profiles/tools/wave_trace_transport.py [rows]
+    FCPT_LIB_PATH=$PWD/fargocpt_amd/libfargocpt_hip_tftrace.so python profiles/tools/wave_trace_transport.py [isothermal|ideal] [nr nphi]
 """
-import os, sys
+import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch  # noqa: F401
 import fargocpt_amd
 from fargocpt_amd import binding as B, driver, setups
 lib = fargocpt_amd.load()
-NR, NPHI = 2048, 4096
-d = setups.planet_disk(lib, NR, NPHI)
+adi = len(sys.argv) > 1 and sys.argv[1] == "ideal"
+NR, NPHI = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2048, 4096)
+d = setups.planet_disk(lib, NR, NPHI, adiabatic=adi)
 ctx = driver.make_context(lib, d, bodies=setups.jupiter_bodies(d))
-if len(sys.argv) > 1:
-    ctx.set_option("transport_rows", int(sys.argv[1]))
 for _ in range(2):
     ctx.calculate_timestep(ctx.cfl())
 ctx.run_steps(200)
 ctx.synchronize()
-t = ctx.download(B.F_TEMPERATURE).ravel()
+# raw copy of the grid (a download would materialise the lazily derived temperature of the ideal EOS over the records)
+ptr, count = ctx.device_ptr(B.F_TEMPERATURE)
+t = np.zeros(count)
+hip = C.CDLL("libamdhip64.so")
+assert hip.hipMemcpy(t.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(t.nbytes), C.c_int(2)) == 0
 tiles = (NPHI + 52) // 53
 rec = t[:4 * (t.size // 4)].reshape(-1, 4)
 good = (rec[:, 3] >= 1) & (rec[:, 3] <= NR) & (rec[:, 2] >= 0) & (rec[:, 2] < rec[:, 3]) & (rec[:, 1] > rec[:, 0]) & (rec[:, 0] > 0) & (rec[:, 3] == np.floor(rec[:, 3]))

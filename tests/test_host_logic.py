@@ -247,15 +247,27 @@ def test_chunk_tables_of_the_marching_kernels(product, nr, nphi, adiabatic, damp
     empty, the long chunks come first; small grids get no table (equal chunks)."""
     t, s = product.selftest_chunk_tables(nr, nphi, 256, adiabatic, damp, damp)
     if len(t):
-        order = np.argsort(t[:, 0])
-        assert t[order[0], 0] == 0 and t[order[-1], 1] == nr
-        assert np.array_equal(t[order[1:], 0], t[order[:-1], 1])
-        n = t[:, 1] - t[:, 0]
+        tiles = -(-nphi // 53)
+        assert len(t) % 4 == 0
+        live = t[t[:, 2] > t[:, 1]]
+        cover = np.zeros((tiles, nr), dtype=np.int32)
+        for tl, a, b in live:
+            cover[tl, a:b] += 1
+        assert (cover == 1).all()
+        n = live[:, 2] - live[:, 1]
         assert n.min() >= 1
-        k0 = 8 * -(-512 // -(-nphi // 53))            # 8 * ceil(slots per XCD / tiles): the first level
-        assert len(t) > k0 and n[k0 - 8:k0].min() >= 2 * n[-9:-1].max()
-        if damp:                                        # a damping-zone ring counts 1.4: those chunks hold fewer rings
-            assert n[0] < n[k0 - 1]
+        if len(live) > 256 * 4 * 4:                     # several rounds of wavefronts: graded chunks, long ones first
+            c0 = live[live[:, 0] == 0]                  # tile 0 of every chunk, in dispatch order
+            m = c0[:, 2] - c0[:, 1]
+            k0 = 8 * -(-512 // tiles)                   # 8 * ceil(slots per XCD / tiles): the first level
+            assert len(m) > k0 and m[k0 - 8:k0].min() >= 2 * m[-9:-1].max()
+            if damp:                                    # a damping-zone ring counts 1.4: those chunks hold fewer rings
+                assert m[0] < m[k0 - 1]
+        else:                                           # one round: the first wavefronts an XCD receives march the longest chunks
+            x0 = t[(np.arange(len(t)) // 4) % 8 == 0]
+            x0 = x0[x0[:, 2] > x0[:, 1]]
+            mm = x0[:, 2] - x0[:, 1]
+            assert mm[:32].mean() > mm[-32:].mean() and n.min() >= 2
     if len(s):
         segs = -(-nphi // 59)
         assert len(s) % 32 == 0                         # whole workgroups, the same number for each of the 8 XCDs
@@ -274,3 +286,5 @@ def test_chunk_tables_of_the_marching_kernels(product, nr, nphi, adiabatic, damp
         assert per_xcd * 8 == len(s)
     if nr * nphi <= 512 * 1536:
         assert len(t) == 0 and len(s) == 0
+    if (nr, nphi) == (1024, 3072):
+        assert 0 < len(t[t[:, 2] > t[:, 1]]) <= 4096    # config 3: one round, rank-matched
