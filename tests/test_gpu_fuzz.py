@@ -95,6 +95,10 @@ def draw(lib, seed):
     # (Pframeforce.cpp:96-189), in every source path (marching, per-loop) and integrator
     if rng.integers(5) == 0:
         d.body_force_from_potential = 0
+    # appended draw (round 3): an explicit, ragged list of chunk lengths for the fused transport kernel (the table path
+    # of k_transport_fused, which the built-in choice only takes on grids far larger than these)
+    if rng.integers(3) == 0:
+        _EXTRA["transport_chunks"] = [int(v) for v in rng.integers(1, 1 + max(2, d.nr_global // 2), size=int(rng.integers(1, 7)))]
     return d, nslabs, planet
 
 

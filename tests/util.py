@@ -29,7 +29,7 @@ def perturb(fields, d, amp=1e-3):
 
 
 def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=(1, 1), dt_scale=1.0, noise=0.0,
-             irradiation=None):
+             irradiation=None, transport_chunks=None):
     """Advance the same initial state `nsteps` with two libraries; returns the two global
     states and the two dt histories."""
     outs = []
@@ -56,6 +56,8 @@ def run_pair(lib_a, lib_b, d, nsteps, bodies=None, amp=1e-3, snap=False, nslabs=
             sub = (fields[0][sl], fields[1][s.imin:s.imin + s.nr + 1], fields[2][sl], fields[3][sl])
             sub = tuple(np.ascontiguousarray(x) for x in sub)
             ctxs.append(driver.make_context(L, dd, fields=sub, radii=radii, bodies=bodies, irradiation=irradiation))
+            if transport_chunks is not None and L.has("set_transport_chunks"):   # (the product's marching kernel; the oracle has no chunks)
+                ctxs[-1].set_transport_chunks(transport_chunks)
         S = driver.SlabSet(ctxs)
         S.dt_scale = dt_scale
         S.prepare()
