@@ -150,7 +150,7 @@ struct Options {
     int theta_march;        // 0: per-pass azimuthal kernels
     int theta_fused;        // 0: same (older name, kept)
     int cfl_rings;          // 0: k_ring_mean + k_cfl_cells instead of k_cfl_rings
-    int cfl_wide_blocks;    // rings of 2049 .. 4096 cells: 0: k_cfl_rings with 256 threads per ring, 1: 1024 threads and all loads ahead of the ring sum, -1: built-in (isothermal 1, ideal EOS 0)
+    int cfl_wide_blocks;    // rings of 2049 .. 4096 cells: 0: k_cfl_rings with 256 threads per ring, 1 | 2: 1024 | 512 threads and all loads ahead of the ring sum, -1: built-in (isothermal 2, ideal EOS 0)
     int cfl_split;          // fcpt_cfl_begin evaluates the interior rings ahead of the ghost exchange
     int source_ring_parts;  // 0: the transport's ring mean re-reads v_phi
     int fused_damping;      // 0: the wave damping as separate kernels in the final boundary call

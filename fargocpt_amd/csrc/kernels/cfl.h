@@ -250,7 +250,7 @@ template <bool ADI, int MAXP, int NT = 256> __global__ void CFL_RINGS_ATTR k_cfl
 {
     const int b = xcd_block(blockIdx.x, gridDim.x); // neighbouring rings share the v_r row between them: same L2
     const int i = b < n1 ? r1 + b : r2 + (b - n1);
-    cfl_ring_block<ADI, MAXP, NT, (NT >= 1024)>(P, part, i);
+    cfl_ring_block<ADI, MAXP, NT, (NT >= 512)>(P, part, i);
     if (finalize && cfl_last_workgroup(P.cfl_tickets, blockIdx.x, gridDim.x))
         cfl_fold(P, part, P.nr, finalize - 1);
 }
@@ -291,7 +291,7 @@ template <bool ADI, int MAXP, int NT = 256> __global__ void CFL_RINGS_ATTR k_cfl
         while (__hip_atomic_load(flag + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq)
             __builtin_amdgcn_s_sleep(2);
     }
-    cfl_ring_block<ADI, MAXP, NT, (NT >= 1024)>(P, part, i);
+    cfl_ring_block<ADI, MAXP, NT, (NT >= 512)>(P, part, i);
 }
 // The last step of the reduction by one workgroup: fold the partial maxima, add the FARGO shear limit, leave the
 // result in the device clock (and apply the CalculateTimeStep policy for device-resident loops).

@@ -956,10 +956,14 @@ bool cfl_by_rings(const Dev &P)
 // of 256 with eight.  Isothermal (two grids): 37 -> 33 us at 2048 x 4096 (profiles/r03_ab_cfl_threads.txt).  Ideal EOS
 // (five grids, 100 VGPRs = one 1024-thread workgroup per CU): 65 against 52 us in the bench's units, 0.505-0.508
 // against 0.491-0.496 ms per step (profiles/r03_ab_cfl_hoist.txt) -- it keeps the 256-thread form.
-static bool cfl_wide_blocks(const Dev &P)
+// (round 3, later: 512 threads with four pairs each read 22.7-23.6 us where 1024 with two read 23.8-25.6, the step
+//  0.3187 against 0.3197 ms, three A/B pairs, profiles/r03_ab_cfl_512.txt: the isothermal built-in; ideal EOS 62-65 us
+//  against 56 for its 256-thread form)
+static int cfl_block_form(const Dev &P) // 0: 256 threads per ring, 1: 1024, 2: 512 (the wide forms load everything ahead of the ring sum)
 {
-    return P.opt.cfl_wide_blocks < 0 ? !P.adiabatic : P.opt.cfl_wide_blocks != 0;
+    return P.opt.cfl_wide_blocks < 0 ? (P.adiabatic ? 0 : 2) : P.opt.cfl_wide_blocks;
 }
+static bool cfl_wide_blocks(const Dev &P) { return cfl_block_form(P) != 0; }
 static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, int finalize, hipStream_t st)
 {
     if (n1 + n2 <= 0)
@@ -975,7 +979,12 @@ static void launch_cfl_rings(const Dev &P, int r1, int n1, int r2, int n2, int f
     }
 #endif
     if (!wide && P.nphi > 2048 && cfl_wide_blocks(P)) {
-        if (P.adiabatic)
+        if (cfl_block_form(P) == 2) { // 512 threads with four cell pairs each
+            if (P.adiabatic)
+                KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<true, CFL_MAXP / 2, 512>), dim3(n1 + n2), dim3(512), P, P.cfl_part, r1, n1, r2, finalize);
+            else
+                KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, CFL_MAXP / 2, 512>), dim3(n1 + n2), dim3(512), P, P.cfl_part, r1, n1, r2, finalize);
+        } else if (P.adiabatic)
             KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<true, CFL_MAXP / 4, 1024>), dim3(n1 + n2), dim3(1024), P, P.cfl_part, r1, n1, r2, finalize);
         else
             KLAUNCH(KID_CFL_RINGS, (k_cfl_rings<false, CFL_MAXP / 4, 1024>), dim3(n1 + n2), dim3(1024), P, P.cfl_part, r1, n1, r2, finalize);
@@ -1007,7 +1016,13 @@ void launch_cfl_bc(const Dev &P, int apply_policy, hipStream_t st)
     KLAUNCH(KID_CFL_RINGS_BC, (k_cfl_rings_bc<ADI_, MAXP_, NT_>), dim3((P.nphi + NT_ - 1) / NT_ + P.nr), dim3(NT_), P, P.cfl_part, \
             (P.nphi + NT_ - 1) / NT_)
     if (!wide && P.nphi > 2048 && cfl_wide_blocks(P)) {
-        if (P.adiabatic) {
+        if (cfl_block_form(P) == 2) {
+            if (P.adiabatic) {
+                CFLBC(true, CFL_MAXP / 2, 512);
+            } else {
+                CFLBC(false, CFL_MAXP / 2, 512);
+            }
+        } else if (P.adiabatic) {
             CFLBC(true, CFL_MAXP / 4, 1024);
         } else {
             CFLBC(false, CFL_MAXP / 4, 1024);
