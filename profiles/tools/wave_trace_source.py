@@ -48,6 +48,13 @@ for x in range(8):
     m = (w // per) == x
     pos = (w[m] - x * per) * 8 // per
     print("  xcd %d:" % x, " ".join("%6.1f" % e0[m][pos == q].mean() for q in range(8) if (pos == q).any()), "  start of the last eighth %.1f" % s0[m][pos == pos.max()].mean())
+if ctx.get_option("source_graded") != 0 and len(ctx.source_chunks()):
+    # table order: workgroup b = blockIdx.x runs on XCD b % 8
+    xcd = (w // 4) % 8
+    print("rank-matched table: per XCD wavefronts, rings marched, mean / max end us")
+    for x in range(8):
+        m = xcd == x
+        print("  xcd %d: %5d wavefronts %7d rings  end mean %.1f max %.1f" % (x, m.sum(), (k1[m] - k0[m]).sum(), e0[m].mean(), e0[m].max()))
 ch = w // segs
 print("per chunk: mean end us")
 print(" ".join("%.0f" % e0[ch == c].mean() for c in range(n // segs)))
