@@ -65,6 +65,7 @@ void options_from_environment(Options &o)
     o.transport_fallback = o.transport_split = o.fused_source = o.march_source = o.march_source_adi = 1;
     o.theta_march = o.theta_fused = o.cfl_rings = o.cfl_split = o.source_ring_parts = o.fused_damping = 1;
     o.cfl_wide_blocks = -1;
+    o.cfl_fold_in_source = -1;
     o.inline_potential = 1;
     o.cfl_thermal = 0; // measured: the kernel that stores the terms spills (28 B) and loses more than the CFL pass gains
     o.bc_fold = 1;

@@ -58,6 +58,9 @@ struct fcpt_ctx {
     // fcpt_run_steps (single slab): the final boundary call of the step just taken has not been launched yet -- the next
     // iteration's CFL launch carries it (k_cfl_rings_bc), or flush_deferred_boundary() does.  Never set when the function returns.
     bool bc_deferred = false;
+    // fcpt_run_steps (single slab): the CFL fold + time-step policy of the step about to be taken has not been launched --
+    // the marching source kernel queued next does it in its prologue (or enqueue_kick launches k_cfl_final first)
+    bool fold_pending = false;
     bool cfl_interior = false; // fcpt_cfl_begin evaluated the interior rings of the current state
     bool damp_any = false;     // this slab holds rings of a damping zone
     double *thermal_grid = nullptr; // storage of Dev::cfl_thermal (the view's pointer is null when the option is off)

@@ -42,7 +42,7 @@ struct DevClock {
     unsigned int n_monitor;
     unsigned int n_snapshot;
     unsigned int shear_error; // sticky: k_transport_fused met |dNshift| > 1 in a step launched without fallback
-    unsigned int pad;
+    unsigned int last_dt_pending; // the CFL fold inside the source march left dt but not last_dt (other workgroups were still reading it): clock_advance completes it
     // hydro_dt_logger (hydro_dt_logger.h:13-34): smallest / largest step since the last fcpt_dt_statistics(reset)
     double dt_min, dt_max;
 };
@@ -52,6 +52,10 @@ __device__ __forceinline__ void clock_advance(DevClock *clk, double dt)
 {
     clk->time += dt;
     clk->n_hydro_iter += 1;
+    if (clk->last_dt_pending) { // sim::CalculateTimeStep's last_dt = dt (simulation.cpp:100-118), deferred by cfl_fold_in_step
+        clk->last_dt = dt;
+        clk->last_dt_pending = 0;
+    }
     clk->dt_min = dt < clk->dt_min ? dt : clk->dt_min;
     clk->dt_max = dt > clk->dt_max ? dt : clk->dt_max;
 }
@@ -151,6 +155,7 @@ struct Options {
     int theta_fused;        // 0: same (older name, kept)
     int cfl_rings;          // 0: k_ring_mean + k_cfl_cells instead of k_cfl_rings
     int cfl_wide_blocks;    // rings of 2049 .. 4096 cells: 0: k_cfl_rings with 256 threads per ring, 1 | 2: 1024 | 512 threads and all loads ahead of the ring sum, -1: built-in (isothermal 2, ideal EOS 0)
+    int cfl_fold_in_source; // fcpt_run_steps on one slab: 0: k_cfl_final as its own launch, 1: every workgroup of the marching source kernel folds the partial maxima itself (-1: built-in)
     int cfl_split;          // fcpt_cfl_begin evaluates the interior rings ahead of the ghost exchange
     int source_ring_parts;  // 0: the transport's ring mean re-reads v_phi
     int fused_damping;      // 0: the wave damping as separate kernels in the final boundary call
@@ -165,7 +170,7 @@ struct Options {
 };
 #define FCPT_OPTION_NAMES                                                                                        \
     X(transport_fused) X(transport_rows) X(transport_graded) X(transport_big) X(transport_ladder) X(transport_rank_grade) X(source_rows) X(source_graded) X(theta_rows) X(transport_fallback) X(transport_split)    \
-    X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_wide_blocks) X(cfl_split)   \
+    X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_wide_blocks) X(cfl_fold_in_source) X(cfl_split)   \
     X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(bc_in_cfl) X(comm_overlap) X(comm_loopback) X(graph_steps) X(profile_stride)
 
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.

@@ -80,7 +80,10 @@ void launch_substep3_cooling_only(const Dev &P, hipStream_t st);
 void launch_disk_on_body(const Dev &P, double x, double y, double r_object, double smoothing_fixed, double r_sm, double *out,
                          hipStream_t st);
 void launch_source_fused(const Dev &P, hipStream_t st);
-int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc = false, bool *bc_folded = nullptr);
+int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_folded, bool fold_cfl = false);
+bool source_march_applies(const Dev &P);
+void launch_cfl_final(const Dev &P, int apply_policy, hipStream_t st);
+bool cfl_by_rings(const Dev &P);
 void launch_viscous_fused(const Dev &P, hipStream_t st);
 void launch_derived(const Dev &P, hipStream_t st);
 void launch_pressure(const Dev &P, hipStream_t st);

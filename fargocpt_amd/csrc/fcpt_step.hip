@@ -50,9 +50,17 @@ bool enqueue_kick(fcpt_ctx *c, bool fold_bc = false)
     const Dev &P = c->P;
     hipStream_t st = c->stream;
     c->kick_bc_folded = false;
+    if (c->fold_pending && !c->fused_source) {
+        launch_cfl_final(P, 1, st);
+        c->fold_pending = false;
+    }
     if (c->fused_source) {
         // one pass: (v[, e]) -> (v_b[, e_b]); fold_bc: and the boundary call that follows the first kick of a step
-        const int segs = c->march_source ? launch_source_march(P, st, fold_bc, &c->kick_bc_folded) : 0;
+        const bool fold_cfl = c->fold_pending && c->march_source && source_march_applies(P);
+        if (c->fold_pending && !fold_cfl)
+            launch_cfl_final(P, 1, st);
+        c->fold_pending = false;
+        const int segs = c->march_source ? launch_source_march(P, st, fold_bc, &c->kick_bc_folded, fold_cfl) : 0;
         c->src_parts = segs > 0 ? segs : 0;
         c->kick_energy_b = segs != 0 && P.adiabatic;
         c->qdiff_valid = segs != 0 && P.adiabatic; // the march wrote Q+ - Q- beside Q+ and Q-; the loop kernels do not
@@ -460,7 +468,16 @@ bool graph_wanted(const fcpt_ctx *c)
 // one iteration of the device-resident loop: CFL reduction -> policy kernel -> step -> post
 void enqueue_device_step(fcpt_ctx *c)
 {
-    enqueue_cfl(c, 1);
+    // (built-in: grids below 4 M cells -- measured, profiles/r03_ab_cfl_fold_in_source.txt: 512 x 1536 -2.4 %, 1024 x 3072
+    //  ideal EOS -1.2 %; at 2048 x 4096 the 1 400 workgroups folding 48 KB each cost the kernel what the launch saved)
+    // (the fold of the CFL reduction inside the marching source kernel: Euler steps whose first launch behind the CFL
+    //  reduction -- but for k_potential, which reads no step length -- is that kernel; ring kernel of the reduction in use)
+    const bool frog = c->d.integrator == FCPT_INTEGRATOR_LEAPFROG;
+    const int want = c->P.opt.cfl_fold_in_source;
+    const bool fold = (want < 0 ? (long long)c->P.nr * c->P.nphi < (1ll << 22) : want != 0) && !frog && c->fused_source &&
+                      c->march_source && source_march_applies(c->P) && cfl_by_rings(c->P);
+    enqueue_cfl(c, fold ? 2 : 1);
+    c->fold_pending = fold;
     enqueue_step(c, true, 0.0, c->d.cfl <= 0.8);
     enqueue_post(c, c->P.opt.bc_in_cfl != 0); // (the boundary call may ride in the next iteration's CFL launch)
 }

@@ -295,7 +295,8 @@ template <bool ADI, int MAXP, int NT = 256> __global__ void CFL_RINGS_ATTR k_cfl
 }
 // The last step of the reduction by one workgroup: fold the partial maxima, add the FARGO shear limit, leave the
 // result in the device clock (and apply the CalculateTimeStep policy for device-resident loops).
-__device__ __forceinline__ void cfl_fold(const Dev &P, const double *part, int nparts, int apply_policy)
+// (every thread of the workgroup returns the same value: the maxima and minima fold exactly, in any order)
+__device__ __forceinline__ double cfl_fold_value(const Dev &P, const double *part, int nparts)
 {
     double smax = 0.0;
     for (int n = threadIdx.x; n < nparts; n += blockDim.x)
@@ -319,13 +320,19 @@ __device__ __forceinline__ void cfl_fold(const Dev &P, const double *part, int n
         s_d[wave] = dt;
     }
     __syncthreads();
+    smax = s_s[0], dt = s_d[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+        smax = dmax(smax, s_s[w]);
+        dt = dmin(dt, s_d[w]);
+    }
+    if (nparts > 0)
+        dt = dmin(dt, P.cfl / sqrt(smax));
+    return dt;
+}
+__device__ __forceinline__ void cfl_fold(const Dev &P, const double *part, int nparts, int apply_policy)
+{
+    const double dt = cfl_fold_value(P, part, nparts);
     if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
-            smax = dmax(smax, s_s[w]);
-            dt = dmin(dt, s_d[w]);
-        }
-        if (nparts > 0)
-            dt = dmin(dt, P.cfl / sqrt(smax));
         P.clk->cfl_bits = (unsigned long long)__double_as_longlong(dt);
         if (P.cfl_export)
             *P.cfl_export = dt;
@@ -337,6 +344,27 @@ __device__ __forceinline__ void cfl_fold(const Dev &P, const double *part, int n
             P.clk->dt = rv;
         }
     }
+}
+// The same inside the marching source kernel (fcpt_run_steps on one slab: the kernel is the next launch behind the ring
+// kernel of the CFL reduction): every workgroup folds the nr partial maxima and the shear limit for itself and takes
+// the step length from its own result -- 48 KB of L2 reads per workgroup instead of a 5 us launch of one workgroup in
+// front of the kernel.  Workgroup 0 leaves the result in the device clock for the kernels behind this one.  last_dt is
+// an INPUT of the policy that other workgroups may still have to read: it is completed by clock_advance (the
+// transport of the same step).
+__device__ __forceinline__ double cfl_fold_in_step(const Dev &P)
+{
+    const double dt = cfl_fold_value(P, P.cfl_part, P.nr);
+    const double a = P.cfl_max_var * P.clk->last_dt;
+    const double rv = dt < a ? dt : a;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.clk->cfl_bits = (unsigned long long)__double_as_longlong(dt);
+        if (P.cfl_export)
+            *P.cfl_export = dt;
+        P.clk->cfl_dt = rv;
+        P.clk->dt = rv;
+        P.clk->last_dt_pending = 1;
+    }
+    return rv;
 }
 __global__ void __launch_bounds__(1024) k_cfl_final(const Dev P, const double *part, int nparts, int apply_policy)
 {

@@ -219,3 +219,7 @@ __device__ __forceinline__ void st2_off(double *base, unsigned off, D2 v) { ST2(
 // wavefronts per workgroup of the marching kernels: always launched with 256 threads (a constant instead of
 // blockDim.x, which is a load from the dispatch packet and a wait at the top of every wavefront)
 #define MARCH_WAVES 4
+
+// (cfl.h) the last stage of the CFL reduction and the CalculateTimeStep policy, evaluated by every workgroup of the
+// marching source kernel for itself -- see there
+__device__ __forceinline__ double cfl_fold_in_step(const Dev &P);

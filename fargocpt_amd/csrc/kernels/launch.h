@@ -509,14 +509,23 @@ static int transport_rows(const Dev &P)
 // whole source step in one marching pass (Nphi >= 128); returns 0 if not applicable, else +-segments (> 0: ring sums
 // of v_phi were left for the transport).  fold_bc: the caller's next call is apply_boundary_condition(final = false) on
 // the kick's result -- *bc_folded reports whether the kernel applied it itself (boundary_column on its edge chunks)
-int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_folded)
+// will launch_source_march() take the step?
+bool source_march_applies(const Dev &P)
+{
+    if (P.nphi < 128)
+        return false;
+    if ((long long)(P.nr + 1) * P.nphi >= (1ll << 29))
+        return false; // the kernels address cells by 32-bit byte offsets (ld_off): grids below 4 GiB
+    return !P.adiabatic || P.opt.march_source_adi != 0;
+}
+// fold_cfl: the launch stands directly behind the ring kernel of the CFL reduction (launch_cfl / launch_cfl_bc with
+// apply_policy = 2): its workgroups fold the reduction and apply the time-step policy themselves (cfl_fold_in_step)
+int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_folded, bool fold_cfl)
 {
     if (bc_folded)
         *bc_folded = false;
-    if (P.nphi < 128)
+    if (!source_march_applies(P))
         return 0;
-    if ((long long)(P.nr + 1) * P.nphi >= (1ll << 29))
-        return 0; // the kernels address cells by 32-bit byte offsets (ld_off): grids below 4 GiB
     int bc_fold = 0;
     const bool sched = P.sm_sched_n > 0 && P.opt.source_rows <= 0; // rank-matched chunks (every one of them >= 3 rings)
     {
@@ -530,9 +539,9 @@ int launch_source_march(const Dev &P, hipStream_t st, bool fold_bc, bool *bc_fol
                 *bc_folded = true;
         }
     }
+    if (fold_cfl)
+        bc_fold |= 2;
     if (P.adiabatic) {
-        if (P.opt.march_source_adi == 0)
-            return 0;
         const int rows = source_rows(P);
         const int segs = (P.nphi + MARCH_VALID - 1) / MARCH_VALID;
         const int chunks = (P.nr + 1 + rows - 1) / rows;
@@ -1037,6 +1046,12 @@ void launch_cfl_bc(const Dev &P, int apply_policy, hipStream_t st)
         CFLBC(false, CFL_MAXP, 256);
     }
 #undef CFLBC
+    if (apply_policy != 2)
+        KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
+}
+// the fold a launch_cfl / launch_cfl_bc with apply_policy = 2 left out, for a caller whose marching source kernel did not run after all
+void launch_cfl_final(const Dev &P, int apply_policy, hipStream_t st)
+{
     KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
 }
 // phase 1 of a split CFL: the interior rings only (returns false when the one-block-per-ring kernel does not apply)
@@ -1057,7 +1072,8 @@ void launch_cfl(const Dev &P, int apply_policy, hipStream_t st, bool interior_do
             launch_cfl_rings(P, 0, CFL_EDGE_LO, P.nr - CFL_EDGE_HI, CFL_EDGE_HI, 0, st);
         else
             launch_cfl_rings(P, 0, P.nr, 0, 0, 0, st);
-        KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
+        if (apply_policy != 2) // (2: the marching source kernel queued next folds for itself)
+            KLAUNCH(KID_CFL_INIT, k_cfl_final, dim3(1), dim3(1024), P, (const double *)P.cfl_part, P.nr, apply_policy);
         return;
     }
     KLAUNCH(KID_RING_MEAN, k_ring_mean, dim3((P.nr + 3) / 4), dim3(256), P, 0, (const double *)nullptr, 0, P.ring_pstride);

@@ -91,14 +91,24 @@ __device__ __forceinline__ double visc_corr_march(double dt, double c) { return 
 // ACC: BodyForceFromPotential: no -- the window carries ACCEL_RADIAL (in the potential's place) and ACCEL_AZIMUTHAL of
 // CalculateAccelOnGas instead of the potential (SourceEuler.cpp:348-353, 406-411)
 template <int AV, bool STAB, bool ACC = false> // AV 0: none, 1: TW, 2: SN
-#ifdef SM_TRACE /* (the trace must run at the production occupancy) */
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
-#else
-__global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
-#endif
+// (six wavefronts per SIMD = 80 VGPRs, asked for: the plain kernels settle there by themselves, but one more live value --
+//  the trace's time stamp, the step length from the in-kernel CFL fold -- tips the allocator's own choice to 82 = five)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STAB ? 4 : (ACC ? 5 : 6), STAB ? 4 : (ACC ? 5 : 6))))
+k_source_march(const Dev P, int segs, int rows_per_chunk, int ring_sums, int bc_fold)
 {
     const int lane = threadIdx.x & 63;
     const int nr = P.nr, nphi = P.nphi;
+    // bc_fold bit 1: this launch stands behind the ring kernel of the CFL reduction without k_cfl_final in between --
+    // every workgroup folds the reduction and applies the time-step policy itself (all of its wavefronts: before any returns)
+    double dt;
+    if (bc_fold & 2) { // (into scalar registers, where the value loaded from the clock lives too: two VGPRs less for the whole kernel)
+        const double v = cfl_fold_in_step(P);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v)), hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
+        dt = __hiloint2double((int)hi, (int)lo);
+    } else {
+        dt = P.clk->dt;
+    }
+    bc_fold &= 1;
     int wave, seg, k0, k1;
     if (P.sm_sched) { // (segment, first ring, one past the last) of every wavefront in the order of dispatch: source_schedule()
         wave = __builtin_amdgcn_readfirstlane(blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6));
@@ -125,7 +135,6 @@ __global__ void __launch_bounds__(256) k_source_march(const Dev P, int segs, int
     const int jraw = seg * MARCH_VALID - MARCH_LO + lane;
     const int j = jraw < 0 ? jraw + nphi : (jraw >= nphi ? jraw - nphi : jraw);
     const bool store_lane = lane >= MARCH_LO && lane < MARCH_LO + MARCH_VALID && jraw < nphi;
-    const double dt = P.clk->dt;
     const double C2 = P.art_visc_factor * P.art_visc_factor;
 
 #define NEXT(x) lane_next(x) /* value of cell j+1 */
@@ -380,6 +389,17 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
 {
     const int lane = threadIdx.x & 63;
     const int nr = P.nr, nphi = P.nphi;
+    // bc_fold bit 1: this launch stands behind the ring kernel of the CFL reduction without k_cfl_final in between --
+    // every workgroup folds the reduction and applies the time-step policy itself (all of its wavefronts: before any returns)
+    double dt;
+    if (bc_fold & 2) { // (into scalar registers, where the value loaded from the clock lives too: two VGPRs less for the whole kernel)
+        const double v = cfl_fold_in_step(P);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)__double2loint(v)), hi = __builtin_amdgcn_readfirstlane((unsigned)__double2hiint(v));
+        dt = __hiloint2double((int)hi, (int)lo);
+    } else {
+        dt = P.clk->dt;
+    }
+    bc_fold &= 1;
     int wave, seg, k0, k1;
     if (P.sm_sched) { // (segment, first ring, one past the last) of every wavefront in the order of dispatch: source_schedule()
         wave = __builtin_amdgcn_readfirstlane(blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6));
@@ -406,7 +426,6 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
     const int jraw = seg * MARCH_VALID - MARCH_LO + lane;
     const int j = jraw < 0 ? jraw + nphi : (jraw >= nphi ? jraw - nphi : jraw);
     const bool store_lane = lane >= MARCH_LO && lane < MARCH_LO + MARCH_VALID && jraw < nphi;
-    const double dt = P.clk->dt;
     const double C2 = P.art_visc_factor * P.art_visc_factor;
     const double gm1 = P.gamma - 1.0;
     const double inv_sqrt_gamma = 1.0 / sqrt(P.gamma);
