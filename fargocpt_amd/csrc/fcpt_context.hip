@@ -65,6 +65,7 @@ void options_from_environment(Options &o)
     o.transport_fallback = o.transport_split = o.fused_source = o.march_source = o.march_source_adi = 1;
     o.theta_march = o.theta_fused = o.cfl_rings = o.cfl_split = o.source_ring_parts = o.fused_damping = 1;
     o.cfl_wide_blocks = -1;
+    o.gate_in_boundary = 1;
     o.cfl_fold_in_source = -1;
     o.inline_potential = 1;
     o.cfl_thermal = 0; // measured: the kernel that stores the terms spills (28 B) and loses more than the CFL pass gains
@@ -505,7 +506,7 @@ int fcpt_create(const fcpt_desc *d, const double *radii, fcpt_ctx **out)
     AL(qr, ns) AL(qphi, ns) AL(divv, ns) AL(trr, ns) AL(tpp, ns) AL(trp, nv) AL(qplus, ns) AL(qminus, ns)
     AL(rmpA, ns) AL(rmmA, ns) AL(lpA, ns) AL(lmA, ns) AL(sigA, ns) AL(eA, ns)
     AL(rmpB, ns) AL(rmmB, ns) AL(lpB, ns) AL(lmB, ns) AL(sigB, ns) AL(eB, ns)
-    AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1) AL(shift_jump, 4)
+    AL(vmean, (size_t)nr + 1) AL(vconst, (size_t)nr) AL(nshift, (size_t)nr) AL(clk, 1) AL(shift_jump, 8)
     AL(cfl_part, (size_t)(nr + 256) * (size_t)((nphi + 255) / 256 + 1))
     AL(cfl_tickets, 32)
     P.ring_pstride = nphi / 32 + 4;
@@ -943,7 +944,7 @@ int fcpt_set_clock(fcpt_ctx *c, const fcpt_clock *in)
     k.n_snapshot = in->n_snapshot;
     // (the shift-jump stamps of k_ring_mean are sequence numbers derived from n_hydro_iter: none may survive a clock
     //  that is set back)
-    HIPCHK(hipMemsetAsync(c->P.shift_jump, 0, 4 * sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->P.shift_jump, 0, 8 * sizeof(int), c->stream));
     *c->h_clk = k;
     HIPCHK(hipMemcpyAsync(c->P.clk, c->h_clk, sizeof(DevClock), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -58,6 +58,10 @@ struct fcpt_ctx {
     // fcpt_run_steps (single slab): the final boundary call of the step just taken has not been launched yet -- the next
     // iteration's CFL launch carries it (k_cfl_rings_bc), or flush_deferred_boundary() does.  Never set when the function returns.
     bool bc_deferred = false;
+    // fcpt_run_steps (single slab): the gated azimuthal launch of the fallback transport is queued together with the final
+    // boundary call of the step (one launch); never pending when a function of the ABI returns
+    bool want_gated_deferred = false, gated_pending = false;
+    GatedTheta gated;
     // fcpt_run_steps (single slab): the CFL fold + time-step policy of the step about to be taken has not been launched --
     // the marching source kernel queued next does it in its prologue (or enqueue_kick launches k_cfl_final first)
     bool fold_pending = false;

@@ -156,6 +156,7 @@ struct Options {
     int cfl_rings;          // 0: k_ring_mean + k_cfl_cells instead of k_cfl_rings
     int cfl_wide_blocks;    // rings of 2049 .. 4096 cells: 0: k_cfl_rings with 256 threads per ring, 1 | 2: 1024 | 512 threads and all loads ahead of the ring sum, -1: built-in (isothermal 2, ideal EOS 0)
     int cfl_fold_in_source; // fcpt_run_steps on one slab: 0: k_cfl_final as its own launch, 1: every workgroup of the marching source kernel folds the partial maxima itself (-1: built-in)
+    int gate_in_boundary;   // fcpt_run_steps on one slab: 1: the idle gated launch of the fallback transport and the final boundary call of the step are ONE launch where the boundary call is its own kernel (grids below 4 M cells)
     int cfl_split;          // fcpt_cfl_begin evaluates the interior rings ahead of the ghost exchange
     int source_ring_parts;  // 0: the transport's ring mean re-reads v_phi
     int fused_damping;      // 0: the wave damping as separate kernels in the final boundary call
@@ -170,7 +171,7 @@ struct Options {
 };
 #define FCPT_OPTION_NAMES                                                                                        \
     X(transport_fused) X(transport_rows) X(transport_graded) X(transport_big) X(transport_ladder) X(transport_rank_grade) X(source_rows) X(source_graded) X(theta_rows) X(transport_fallback) X(transport_split)    \
-    X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_wide_blocks) X(cfl_fold_in_source) X(cfl_split)   \
+    X(fused_source) X(march_source) X(march_source_adi) X(theta_march) X(theta_fused) X(cfl_rings) X(cfl_wide_blocks) X(cfl_fold_in_source) X(gate_in_boundary) X(cfl_split)   \
     X(source_ring_parts) X(fused_damping) X(inline_potential) X(cfl_thermal) X(bc_fold) X(bc_in_cfl) X(comm_overlap) X(comm_loopback) X(graph_steps) X(profile_stride)
 
 // Everything a kernel needs: geometry, grids, parameters.  Passed by value.

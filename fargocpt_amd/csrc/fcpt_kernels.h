@@ -19,7 +19,7 @@ enum KernelId {
     KID_VISC_VR, KID_QPLUS, KID_SUBSTEP3, KID_BOUNDARY, KID_DAMPING, KID_TRANSPORT_RADIAL,
     KID_RING_MEAN, KID_THETA1, KID_THETA2, KID_VELOCITIES, KID_CFL_INIT, KID_CFL_CELLS, KID_CLOCK,
     KID_SRC_FUSED, KID_AV_FUSED, KID_VISC_FUSED, KID_SOURCE_MARCH, KID_THETA_MARCH,
-    KID_TRANSPORT_FUSED, KID_MASSFLOW, KID_CFL_RINGS, KID_TRANSPORT_FALLBACK, KID_EXCHANGE_COPY,
+    KID_TRANSPORT_FUSED, KID_MASSFLOW, KID_CFL_RINGS, KID_THETA_GATED_BOUNDARY, KID_EXCHANGE_COPY,
     KID_DISK_ON_BODY, KID_VISC_FACTORS, KID_SOURCE_MARCH_ADI, KID_SOURCE_MARCH_ADI_WIDE,
     KID_TRANSPORT_FUSED_THERM, KID_TRANSPORT_FUSED_WIDE, KID_STEP_COOP, KID_ACCEL_ON_GAS,
     KID_SOURCE_MARCH_ADI_ACC, KID_TRANSPORT_RADIAL_MEANS, KID_CFL_RINGS_BC, KID_COUNT
@@ -66,9 +66,15 @@ struct TransportResult {
     double *sigma, *energy, *vrad, *vazi;
     int split;    // only a part of the chunks was marched
     int thermal;  // the kernel left the cell-local CFL terms of the new state in Dev::cfl_thermal
+    int gated_pending; // launch_transport(defer_gated): the gated azimuthal launch of the fallback is still to be queued (launch_gated_theta)
 };
+// the arguments of that launch, kept by the caller until the final boundary call of the step
+struct GatedTheta {
+    Dev P, Wm;
+};
+void launch_gated_theta(const GatedTheta &g, const Dev *boundary_view, hipStream_t st); // boundary_view != null: + the boundary call, one launch
 enum { TRANSPORT_ALL = 0, TRANSPORT_EDGES = 1, TRANSPORT_INTERIOR = 2 };
-TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part = TRANSPORT_ALL);
+TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part = TRANSPORT_ALL, GatedTheta *defer_gated = nullptr);
 bool transport_can_split(const Dev &P, bool shear_safe);
 std::vector<int> source_schedule(const Dev &P);
 void selftest_chunk_tables(int nr, int nphi, int n_cu, int adiabatic, int damp_inner, int damp_outer, const Options &opt,

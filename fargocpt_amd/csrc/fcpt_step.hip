@@ -176,8 +176,10 @@ void enqueue_step(fcpt_ctx *c, bool dt_dev, double dt, bool shear_safe, bool spl
         tr = launch_transport(Q, P, st, TRANSPORT_EDGES);
         c->join_pending = true;
     } else {
-        tr = launch_transport(Q, P, st);
+        tr = launch_transport(Q, P, st, TRANSPORT_ALL, c->want_gated_deferred && !frog ? &c->gated : nullptr);
+        c->gated_pending = tr.gated_pending != 0;
     }
+    c->want_gated_deferred = false;
     if (!tr.marched)
         launch_clock_advance(P.clk, st);
     // a marching transport kernel stored the cell-local CFL terms with the new Sigma and e; they stay those of the
@@ -234,7 +236,23 @@ void enqueue_post(fcpt_ctx *c, bool may_defer_boundary)
     const bool damping_done = c->P.damp_in_step != 0 && c->stepped;
     // fcpt_run_steps: when the call is nothing but the ghost-ring kernel (no separate damping launches, no derived grids
     // to refresh behind it) and the next launch of the stream is the one-block-per-ring CFL kernel, that launch carries it
-    if (may_defer_boundary && (damping_done || !c->damp_any) && !(c->P.adiabatic && !c->P.lazy_derived) && cfl_bc_mergeable(c->P))
+    const bool defer = may_defer_boundary && (damping_done || !c->damp_any) && !(c->P.adiabatic && !c->P.lazy_derived) && cfl_bc_mergeable(c->P);
+    if (c->gated_pending) { // (enqueue_device_step asked the transport to leave its gated fallback launch to this call)
+        c->gated_pending = false;
+        if (!defer && (damping_done || !c->d.damping)) { // the call is nothing but the ghost-ring kernel: one launch for both
+            launch_gated_theta(c->gated, &c->P, c->stream);
+            c->stepped = false;
+            if (c->P.adiabatic && !c->P.lazy_derived) {
+                launch_derived(c->P, c->stream);
+                c->pressure_valid = true;
+            } else {
+                c->pressure_valid = false;
+            }
+            return;
+        }
+        launch_gated_theta(c->gated, nullptr, c->stream);
+    }
+    if (defer)
         c->bc_deferred = true;
     else
         apply_boundary_view(c, c->P, true, damping_done);
@@ -478,6 +496,14 @@ void enqueue_device_step(fcpt_ctx *c)
                       c->march_source && source_march_applies(c->P) && cfl_by_rings(c->P);
     enqueue_cfl(c, fold ? 2 : 1);
     c->fold_pending = fold;
+    {
+        // the gated launch of the fallback transport together with the final boundary call, where that call will be
+        // nothing but the ghost-ring kernel and does not ride in the next CFL launch (grids below 4 M cells)
+        const bool pure_bc = (c->P.damp_in_step != 0 || !c->d.damping) && !(c->P.adiabatic && !c->P.lazy_derived);
+        const bool rides_in_cfl = c->P.opt.bc_in_cfl != 0 && (c->P.damp_in_step != 0 || !c->damp_any) &&
+                                  !(c->P.adiabatic && !c->P.lazy_derived) && cfl_bc_mergeable(c->P);
+        c->want_gated_deferred = c->P.opt.gate_in_boundary != 0 && !frog && pure_bc && !rides_in_cfl;
+    }
     enqueue_step(c, true, 0.0, c->d.cfl <= 0.8);
     enqueue_post(c, c->P.opt.bc_in_cfl != 0); // (the boundary call may ride in the next iteration's CFL launch)
 }

@@ -10,7 +10,7 @@ const char *const kKernelNames[KID_COUNT] = {
     "k_visc_vr", "k_qplus_qminus", "k_substep3", "k_boundary", "k_damping", "k_transport_radial",
     "k_ring_mean", "k_transport_theta<1>", "k_transport_theta<2>", "k_velocities", "k_cfl_final",
     "k_cfl_cells", "k_clock", "k_src_fused", "k_av_fused", "k_visc_fused", "k_source_march",
-    "k_transport_theta_march", "k_transport_fused", "k_massflow", "k_cfl_rings", "k_transport_fallback",
+    "k_transport_theta_march", "k_transport_fused", "k_massflow", "k_cfl_rings", "k_theta_march_gated_boundary",
     "k_exchange_copy", "k_disk_on_body", "k_visc_factors", "k_source_march_adi", "k_source_march_adi_wide",
     "k_transport_fused_therm", "k_transport_fused_wide", "k_step_coop", "k_accel_on_gas", "k_source_march_adi_acc",
     "k_transport_radial_means", "k_cfl_rings_bc"};
@@ -764,6 +764,41 @@ static int launch_theta_march(const Dev &P, const Dev &Wm, int C, int periodic, 
     }
     return tiles;
 }
+// the gated azimuthal launch launch_transport(defer_gated) left out -- alone, or with the final boundary call of the step
+// on `boundary_view` (the state after the transport's pointer swap) in the same launch (k_theta_march_gated_boundary)
+void launch_gated_theta(const GatedTheta &g, const Dev *boundary_view, hipStream_t st)
+{
+    const Dev &P = g.P, &Wm = g.Wm;
+    if (!boundary_view) {
+        launch_theta_march(P, Wm, 2, 0, 0, P.shift_jump, st);
+        return;
+    }
+    ThetaSet inB = {P.rmpB, P.rmmB, P.lpB, P.lmB, P.sigB, P.eB};
+    const int tstride = 64 * 2 - (THETA_LO + THETA_HI);
+    const int tiles = (P.nphi + tstride - 1) / tstride;
+    const int rows = P.opt.theta_rows > 0 ? P.opt.theta_rows : march_len(P, THETA_ROWS);
+    const int chunks = (P.nr + rows - 1) / rows;
+    const int nvb = (chunks * tiles + 3) / 4;
+    const int ntheta = nvb > FALLBACK_BLOCKS ? FALLBACK_BLOCKS : nvb;
+    const dim3 grid(ntheta + (boundary_view->nphi + 255) / 256), block(256);
+#define GTB(AA, DD)                                                                                                       \
+    KLAUNCH(KID_THETA_GATED_BOUNDARY, (k_theta_march_gated_boundary<2, AA, DD, false>), grid, block, Wm, (const double *)P.vazi, \
+            (const double *)P.vrad, inB, tiles, rows, nvb, ntheta, *boundary_view)
+    if (P.adiabatic) {
+        if (Wm.damp_in_step) {
+            GTB(true, true);
+        } else {
+            GTB(true, false);
+        }
+    } else {
+        if (Wm.damp_in_step) {
+            GTB(false, true);
+        } else {
+            GTB(false, false);
+        }
+    }
+#undef GTB
+}
 #undef MARCHC
 #undef MARCHK
 
@@ -786,11 +821,11 @@ bool transport_can_split(const Dev &P, bool shear_safe)
 // part: TRANSPORT_ALL, or -- for slabs with neighbours, when transport_can_split() -- launch_shift_means, then
 // TRANSPORT_INTERIOR on a side stream and TRANSPORT_EDGES (the chunks holding the rings a neighbour receives, rows
 // [7,14) and [nr-14,nr-7)) on the caller's stream, so that the ghost exchange runs under the interior chunks.
-TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part)
+TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int part, GatedTheta *defer_gated)
 {
     // P: view whose vrad/vazi are the velocities to transport; W: view that receives the new state
     // Transport, TransportEuler.cpp:112-136
-    TransportResult res = {0, W.sigma, W.energy, W.vrad, W.vazi, 0, 0};
+    TransportResult res = {0, W.sigma, W.energy, W.vrad, W.vazi, 0, 0, 0};
     // ---- everything in one kernel (tiled rings only) ------------------------------------------
     int CF = P.nphi >= 256 ? 1 : 0; // 1 cell per lane: 3 waves per SIMD (2 cells: 284 VGPRs, 1 wave)
     if (P.opt.transport_fused >= 0) { // 0: off, 1 / 2: cells per lane
@@ -872,8 +907,13 @@ TransportResult launch_transport(const Dev &P, const Dev &W, hipStream_t st, int
         // |Nshift[i] - Nshift[i-1]| > 1 (a time step beyond the FARGO shear limit) -- the fused launch then ran the
         // radial sweep.  (Round 2 did both sweeps in this second launch with a hand-rolled grid barrier between them;
         // the flag now being known before the fused launch starts, no barrier is needed.)
-        if (fallback)
+        if (fallback && defer_gated && part == TRANSPORT_ALL) { // the caller queues it with the final boundary call (launch_gated_theta)
+            defer_gated->P = P;
+            defer_gated->Wm = Wm;
+            res.gated_pending = 1;
+        } else if (fallback) {
             launch_theta_march(P, Wm, 2, 0, 0, P.shift_jump, st);
+        }
         res.marched = tiles;
         res.thermal = CF == 1 && P.adiabatic && Wm.cfl_thermal != nullptr;
         res.sigma = Wm.sigma, res.energy = Wm.energy, res.vrad = Wm.vrad, res.vazi = Wm.vazi;

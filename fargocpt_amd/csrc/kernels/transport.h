@@ -890,6 +890,44 @@ __device__ __forceinline__ void transport_theta_march_block(const Dev &P, const 
 #undef SH_NEXT
 }
 
+// The gated azimuthal march of the fallback transport AND the final boundary call of the step in one launch
+// (fcpt_run_steps on grids whose boundary call is its own kernel: one dependent launch of ~5 us less per step).
+// Workgroups [0, ntheta): the march, as k_transport_theta_march with only_if -- they return at once unless
+// k_ring_mean raised the flag; workgroups behind them: boundary_column on the view B (the state after the
+// transport's pointer swap), one column per thread.  Only in the rare step that falls back do the boundary
+// workgroups wait -- for the stamp the last marching workgroup publishes (flag[4]: arrivals, flag[5]: stamp = this
+// transport's sequence number; the marching workgroups have the lower indices and never wait: no deadlock).
+template <int C, bool ADI, bool DAMP, bool PER>
+__global__ void __launch_bounds__(256) k_theta_march_gated_boundary(const Dev P, const double *va_pre, const double *vr_pre, ThetaSet in,
+                                                                    int tiles, int rows, int nvb, int ntheta, const Dev B)
+{
+    int *flag = P.shift_jump;
+    const bool raised = shift_jump_raised(flag);
+    if ((int)blockIdx.x < ntheta) {
+        if (!raised)
+            return;
+        for (int vb = blockIdx.x; vb < nvb; vb += ntheta)
+            transport_theta_march_block<C, ADI, DAMP, PER>(P, va_pre, vr_pre, in, tiles, rows, 0, vb, nvb);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence(); // the workgroup's part of the new state is visible device-wide before it reports in
+            if (__hip_atomic_fetch_add(flag + 4, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == ntheta - 1) {
+                __hip_atomic_store(flag + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(flag + 5, flag[2], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    if (raised) {
+        const int seq = flag[2];
+        while (__hip_atomic_load(flag + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq)
+            __builtin_amdgcn_s_sleep(2);
+    }
+    const int j = ((int)blockIdx.x - ntheta) * blockDim.x + threadIdx.x;
+    if (j < B.nphi)
+        boundary_column(B, j, 3);
+}
+
 // grid-stride wrapper, as k_transport_radial
 template <int C, bool ADI, bool DAMP, bool PER>
 __global__ void __launch_bounds__(256) k_transport_theta_march(const Dev P, const double *va_pre, const double *vr_pre, ThetaSet in,

@@ -312,7 +312,7 @@ int fcpt_synchronize(fcpt_ctx *ctx);
  * environment variables FCPT_<NAME> only provide the defaults read once in fcpt_create; no launch reads the
  * environment.  -1 = the library's built-in choice.  Names: transport_fused (0 | 1 | 2), transport_rows, transport_graded, transport_big, transport_ladder, transport_rank_grade, source_graded,
  * source_rows, theta_rows, transport_fallback, transport_split, fused_source, march_source, march_source_adi,
- * theta_march, theta_fused, cfl_rings, cfl_wide_blocks, cfl_fold_in_source, cfl_split, source_ring_parts, fused_damping, inline_potential, cfl_thermal, bc_fold, bc_in_cfl, comm_overlap,
+ * theta_march, theta_fused, cfl_rings, cfl_wide_blocks, cfl_fold_in_source, gate_in_boundary, cfl_split, source_ring_parts, fused_damping, inline_potential, cfl_thermal, bc_fold, bc_in_cfl, comm_overlap,
  * comm_loopback, graph_steps, profile_stride (fcpt_profile_start times every n-th launch of the selected kernels).
  * fcpt_get_option also answers three read-only counters of fcpt_run_steps: graph_replays (hipGraphLaunch calls issued
  * so far), graph_cycle (steps per replay, 0 = no graph), coop_active (always 0: a one-kernel step was measured slower than
