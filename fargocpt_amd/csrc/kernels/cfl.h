@@ -301,30 +301,34 @@ __device__ __forceinline__ double cfl_fold_value(const Dev &P, const double *par
     double smax = 0.0;
     for (int n = threadIdx.x; n < nparts; n += blockDim.x)
         smax = dmax(smax, part[n]);
-    // FARGO shear limit, rings 0|1 (:207-208) and the active rings (:213-220)
-    double dt = 1.0e300;
+    // FARGO shear limit, rings 0|1 (:207-208) and the active rings (:213-220): the smallest of cfl dphi / denom over the
+    // ring pairs IS cfl dphi / (the largest denom) -- a correctly rounded quotient is monotone in its divisor -- so the
+    // pairs are folded by their denominators and divided once (an IEEE division per pair was most of this function's
+    // vector work, which every workgroup of the marching source kernel repeats when the fold runs in its prologue)
+    double dmx = 0.0;
     for (int n = threadIdx.x; n < P.active_size; n += blockDim.x) {
         if (n == 0 || n >= P.first_active) {
             const double denom = fabs(P.vmean[n] * P.InvRmed[n] - P.vmean[n + 1] * P.InvRmed[n + 1]) + 1.0e-100;
-            dt = dmin(dt, P.cfl * P.dphi / denom);
+            dmx = dmax(dmx, denom);
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
         smax = dmax(smax, __shfl_down(smax, off, 64));
-        dt = dmin(dt, __shfl_down(dt, off, 64));
+        dmx = dmax(dmx, __shfl_down(dmx, off, 64));
     }
     __shared__ double s_s[16], s_d[16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) {
         s_s[wave] = smax;
-        s_d[wave] = dt;
+        s_d[wave] = dmx;
     }
     __syncthreads();
-    smax = s_s[0], dt = s_d[0];
+    smax = s_s[0], dmx = s_d[0];
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
         smax = dmax(smax, s_s[w]);
-        dt = dmin(dt, s_d[w]);
+        dmx = dmax(dmx, s_d[w]);
     }
+    double dt = dmx > 0.0 ? P.cfl * P.dphi / dmx : 1.0e300; // (no pair at all: no limit)
     if (nparts > 0)
         dt = dmin(dt, P.cfl / sqrt(smax));
     return dt;
