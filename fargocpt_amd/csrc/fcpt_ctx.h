@@ -58,6 +58,7 @@ struct fcpt_ctx {
     // fcpt_run_steps (single slab): the final boundary call of the step just taken has not been launched yet -- the next
     // iteration's CFL launch carries it (k_cfl_rings_bc), or flush_deferred_boundary() does.  Never set when the function returns.
     bool bc_deferred = false;
+    bool skip_q_store = false; // fcpt_run_steps: the step about to be queued is not the call's last (Dev::q_skip for its kick)
     // fcpt_run_steps (single slab): the gated azimuthal launch of the fallback transport is queued together with the final
     // boundary call of the step (one launch); never pending when a function of the ABI returns
     bool want_gated_deferred = false, gated_pending = false;

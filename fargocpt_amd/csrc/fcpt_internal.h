@@ -189,6 +189,7 @@ struct Dev {
     //   g_dxtheta = dphi Rmed, g_inv_dxtheta = 1/(dphi Rmed), g_dr_invsurf = (Rsup-Rinf) InvSurf, g_r_omega = Rmed OmegaFrame
     CArr g_dxtheta, g_inv_dxtheta, g_dr_invsurf, g_r_omega;
     CArr g_inv_omk;  // 1 / Omega_K(Rmed[i])
+    int q_skip;       // 1: k_source_march_adi leaves Q+ and Q- unwritten (only their difference, which the CFL kernel reads): set for the steps of fcpt_run_steps that are not its last
     int lazy_derived; // ideal EOS + marching source step: c_s, H, nu, T, P are formed in registers where needed,
                       // the grids are only materialised for callers that ask for them
     int inline_potential; // ... and the potential of the Euler step inside k_source_march_adi

@@ -60,7 +60,15 @@ bool enqueue_kick(fcpt_ctx *c, bool fold_bc = false)
         if (c->fold_pending && !fold_cfl)
             launch_cfl_final(P, 1, st);
         c->fold_pending = false;
-        const int segs = c->march_source ? launch_source_march(P, st, fold_bc, &c->kick_bc_folded, fold_cfl) : 0;
+        int segs = 0;
+        if (c->march_source && c->skip_q_store && P.adiabatic && cfl_by_rings(P) && !P.cfl_thermal) {
+            Dev Q = P; // (Q+ and Q- themselves are read by nothing on the device in this configuration: the ring kernel of the CFL reduction takes their difference)
+            Q.q_skip = 1;
+            segs = launch_source_march(Q, st, fold_bc, &c->kick_bc_folded, fold_cfl);
+        } else if (c->march_source) {
+            segs = launch_source_march(P, st, fold_bc, &c->kick_bc_folded, fold_cfl);
+        }
+        c->skip_q_store = false;
         c->src_parts = segs > 0 ? segs : 0;
         c->kick_energy_b = segs != 0 && P.adiabatic;
         c->qdiff_valid = segs != 0 && P.adiabatic; // the march wrote Q+ - Q- beside Q+ and Q-; the loop kernels do not
@@ -572,6 +580,7 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
             if (int rc = enqueue_cfl_allreduce(c))
                 return rc;
             launch_clock_policy_ptr(c->P.clk, c->d.cfl_max_var, c->d_cfl, c->stream);
+            c->skip_q_store = c->d.integrator != FCPT_INTEGRATOR_LEAPFROG && n + 1 < nsteps; // Q+ / Q- (outputs) by the last step only
             enqueue_step(c, true, 0.0, c->d.cfl <= 0.8);
             if (int rc = enqueue_exchange(c))
                 return rc;
@@ -636,8 +645,11 @@ int fcpt_run_steps(fcpt_ctx *c, int64_t nsteps, int32_t snap, int64_t *done)
                 }
             }
         }
-        for (; n < nsteps; ++n)
+        const bool frog_loop = c->d.integrator == FCPT_INTEGRATOR_LEAPFROG;
+        for (; n < nsteps; ++n) {
+            c->skip_q_store = !frog_loop && n + 1 < nsteps; // Q+ / Q- (outputs) by the last step only
             enqueue_device_step(c);
+        }
         flush_deferred_boundary(c); // the last step's boundary call has no CFL launch to ride in
         HIPCHK(hipGetLastError());
     } else {

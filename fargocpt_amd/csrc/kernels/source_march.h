@@ -741,8 +741,10 @@ __device__ __forceinline__ void source_march_adi_body(const Dev &P, int segs, in
                     if (k < nr) {
                         ADI_ST(P.vazi_b, k, va3);
                         ADI_ST(P.energy_b, k, e);
-                        ADI_ST(P.qplus, k, qplus);
-                        ADI_ST(P.qminus, k, qminus);
+                        if (!P.q_skip) { // (the grids are outputs: fcpt_run_steps has them written by its last step only -- two of ten grids of traffic)
+                            ADI_ST(P.qplus, k, qplus);
+                            ADI_ST(P.qminus, k, qminus);
+                        }
                         ADI_ST(P.qdiff, k, qplus - qminus); // what the CFL condition needs of the two (cfl.cpp:303-316)
                         // step_LeapFrog evaluates the mid-step potential with the scale height this kick's
                         // recalculate_viscosity left behind (simulation.cpp:340-378), not with that of the

@@ -766,6 +766,36 @@ def test_transport_chunk_lengths_never_change_a_result(product, case):
         assert np.array_equal(out[0][0][k], out[1][0][k]), k
 
 
+def test_heating_grids_after_the_device_loop(product):
+    """fcpt_run_steps lets only its LAST step write Q+ and Q- (outputs of the ideal-EOS source step; the steps before
+    leave their difference for the CFL kernel and save two grids of traffic): after the call the grids must be those
+    of the last step, bit for bit what the host-driven loop leaves -- also when the next call is one step long."""
+    from fargocpt_amd import driver
+    d = setups.planet_disk(product, 72, 320, adiabatic=True)
+    bodies = setups.jupiter_bodies(d)
+    out = []
+    for device_loop in (True, False):
+        ctx = driver.make_context(product, d, bodies=bodies)
+        S = driver.SlabSet([ctx])
+        S.prepare()
+        if device_loop:
+            assert ctx.run_steps(7) == 7
+            mid = (ctx.download(B.F_QPLUS).copy(), ctx.download(B.F_QMINUS).copy())
+            assert ctx.run_steps(1) == 1
+        else:
+            S.run(7)
+            mid = (ctx.download(B.F_QPLUS).copy(), ctx.download(B.F_QMINUS).copy())
+            S.run(1)
+        out.append((mid, ctx.download(B.F_QPLUS).copy(), ctx.download(B.F_QMINUS).copy(), ctx.state()))
+        ctx.close()
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert np.abs(out[0][1]).max() > 0.0
+    for k in out[0][3]:
+        assert np.array_equal(out[0][3][k], out[1][3][k]), k
+
+
 @pytest.mark.parametrize("nslabs", [1, 2])
 def test_cfl_thermal_option(product, oracle, nslabs, monkeypatch):
     """Option cfl_thermal (off by default: measured slower at 2048 x 4096): the marching transport stores the
